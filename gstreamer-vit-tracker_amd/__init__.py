@@ -1,0 +1,457 @@
+"""MI355X-native ViT tracker hot path — Python bindings over the C ABI (include/vittrack_hip.h).
+
+The classes mirror the reference's `vit_tracker` crate surface as its host uses it
+(/root/reference/src/tracker_context.rs:2,21,88,90,94,120; src/selection_state.rs:1,44):
+`VitTrack.new / init / update`, `BBox.new / from_array`. They are thin ctypes wrappers: all
+computation happens in libvittrack_hip.so (hand-written gfx950 kernels). There is no CPU
+fallback — without the built library or without a gfx950 device every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int,
+                    c_int32, c_int64, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p)
+
+import numpy as np
+
+from . import weights  # noqa: F401  (blob writer / configs)
+from . import synth    # noqa: F401
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libvittrack_hip.so")
+
+PIX_RGB8, PIX_NV12 = 0, 1
+
+
+class VtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"vittrack_hip error {code}: {text}")
+        self.code = code
+
+
+class CBBox(Structure):
+    _fields_ = [("x", c_int32), ("y", c_int32), ("width", c_int32), ("height", c_int32)]
+
+
+class CResult(Structure):
+    _fields_ = [("success", c_int32), ("score", c_float), ("bbox", CBBox)]
+
+
+class CConfig(Structure):
+    _fields_ = [("struct_size", c_uint32), ("success_threshold", c_float), ("use_graph", c_int32),
+                ("n_streams", c_int32), ("max_frame_width", c_int32),
+                ("max_frame_height", c_int32), ("reserved", c_int32 * 8)]
+
+
+class CModelInfo(Structure):
+    _fields_ = [("patch", c_int32), ("template_size", c_int32), ("search_size", c_int32),
+                ("dim", c_int32), ("heads", c_int32), ("layers", c_int32), ("mlp_dim", c_int32),
+                ("head_channels", c_int32), ("tokens_template", c_int32),
+                ("tokens_search", c_int32), ("kpad", c_int32), ("score_grid", c_int32),
+                ("flops_per_frame", c_double), ("encoder_flops_per_frame", c_double),
+                ("weight_bytes", c_uint64)]
+
+
+class CFrame(Structure):
+    _fields_ = [("plane0", c_void_p), ("plane1", c_void_p), ("width", c_int32),
+                ("height", c_int32), ("stride0", c_int32), ("stride1", c_int32),
+                ("format", c_int32), ("reserved", c_int32)]
+
+
+class CKernelTime(Structure):
+    _fields_ = [("name", c_char * 48), ("launches", c_int32), ("ms_total", c_float),
+                ("flops", c_double), ("bytes", c_double)]
+
+
+_lib = None
+
+# every symbol include/vittrack_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "vt_config_default", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_create",
+    "vt_create_from_device_blob", "vt_destroy", "vt_get_model_info", "vt_init_rgb8",
+    "vt_update_rgb8", "vt_init_nv12", "vt_update_nv12", "vt_init_rgb8_device",
+    "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
+    "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
+    "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
+    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device",
+    "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
+    "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_qkv_bf16", "vt_op_attention_bf16",
+    "vt_op_layernorm",
+]
+
+
+def lib():
+    """Load libvittrack_hip.so (built in-tree by build.py). Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtError(-2, f"{LIB_PATH} not built: run `python __graft_entry__.py` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.vt_last_error.restype = c_char_p
+    L.vt_config_default.argtypes = [POINTER(CConfig)]
+    L.vt_create.argtypes = [c_char_p, c_int, POINTER(CConfig), POINTER(c_void_p)]
+    L.vt_create_from_device_blob.argtypes = [c_void_p, c_size_t, c_int, POINTER(CConfig),
+                                             POINTER(c_void_p)]
+    L.vt_destroy.argtypes = [c_void_p]
+    L.vt_destroy.restype = None
+    L.vt_get_model_info.argtypes = [c_void_p, POINTER(CModelInfo)]
+    u8p = POINTER(c_uint8)
+    L.vt_init_rgb8.argtypes = [c_void_p, u8p, c_int, c_int, c_int, CBBox]
+    L.vt_update_rgb8.argtypes = [c_void_p, u8p, c_int, c_int, c_int, POINTER(CResult)]
+    L.vt_init_nv12.argtypes = [c_void_p, u8p, u8p, c_int, c_int, c_int, c_int, CBBox]
+    L.vt_update_nv12.argtypes = [c_void_p, u8p, u8p, c_int, c_int, c_int, c_int, POINTER(CResult)]
+    L.vt_init_rgb8_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, CBBox]
+    L.vt_update_rgb8_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(CResult)]
+    L.vt_init_nv12_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      CBBox]
+    L.vt_update_nv12_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        POINTER(CResult)]
+    L.vt_group_create.argtypes = [c_char_p, c_int, POINTER(CConfig), POINTER(c_void_p)]
+    L.vt_group_create_from_device_blob.argtypes = [c_void_p, c_size_t, c_int, POINTER(CConfig),
+                                                   POINTER(c_void_p)]
+    L.vt_group_destroy.argtypes = [c_void_p]
+    L.vt_group_destroy.restype = None
+    L.vt_group_streams.argtypes = [c_void_p]
+    L.vt_group_get_model_info.argtypes = [c_void_p, POINTER(CModelInfo)]
+    L.vt_group_init_device.argtypes = [c_void_p, c_int, POINTER(CFrame), CBBox]
+    L.vt_group_enqueue_device.argtypes = [c_void_p, POINTER(CFrame), c_int]
+    L.vt_group_wait.argtypes = [c_void_p, POINTER(CResult), c_int]
+    L.vt_group_update_device.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
+    L.vt_group_hip_stream.argtypes = [c_void_p]
+    L.vt_group_hip_stream.restype = c_void_p
+    L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
+                                          POINTER(CKernelTime), c_int]
+    L.vt_group_enable_taps.argtypes = [c_void_p, c_int]
+    L.vt_tracker_as_group.argtypes = [c_void_p]
+    L.vt_tracker_as_group.restype = c_void_p
+    L.vt_group_read_tensor.argtypes = [c_void_p, c_int, c_char_p, POINTER(c_float), c_int64]
+    L.vt_group_read_tensor.restype = c_int64
+    L.vt_nv12_to_rgb8.argtypes = [c_int, u8p, c_size_t, c_int, c_int, u8p]
+    L.vt_nv12_to_rgb8_device.argtypes = [c_int, c_void_p, c_size_t, c_int, c_int, c_void_p,
+                                         c_void_p]
+    u16p, fp = POINTER(c_uint16), POINTER(c_float)
+    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int]
+    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int]
+    L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int]
+    L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise VtError(rc, lib().vt_last_error().decode(errors="replace"))
+    return rc
+
+
+def device_count() -> int:
+    return lib().vt_device_count()
+
+
+def _u8(a):
+    return a.ctypes.data_as(POINTER(c_uint8))
+
+
+def _u16(a):
+    return a.ctypes.data_as(POINTER(c_uint16))
+
+
+def _f32(a):
+    return a.ctypes.data_as(POINTER(c_float))
+
+
+def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, max_h=0) -> CConfig:
+    c = CConfig()
+    lib().vt_config_default(byref(c))
+    c.success_threshold = success_threshold
+    c.use_graph = 1 if use_graph else 0
+    c.n_streams = n_streams
+    c.max_frame_width, c.max_frame_height = max_w, max_h
+    return c
+
+
+# ---- reference-shaped API ---------------------------------------------------------------------
+
+class BBox:
+    """≙ vit_tracker::BBox (src/selection_state.rs:44, src/tracker_context.rs:94)."""
+    __slots__ = ("x", "y", "width", "height")
+
+    def __init__(self, x, y, width, height):
+        self.x, self.y, self.width, self.height = int(x), int(y), int(width), int(height)
+
+    @staticmethod
+    def new(x, y, width, height):
+        return BBox(x, y, width, height)
+
+    @staticmethod
+    def from_array(a):
+        return BBox(int(a[0]), int(a[1]), int(a[2]), int(a[3]))
+
+    def as_tuple(self):
+        return (self.x, self.y, self.width, self.height)
+
+    def _c(self):
+        return CBBox(self.x, self.y, self.width, self.height)
+
+    def __eq__(self, o):
+        return isinstance(o, BBox) and self.as_tuple() == o.as_tuple()
+
+    def __repr__(self):
+        return f"BBox(x={self.x}, y={self.y}, width={self.width}, height={self.height})"
+
+
+class TrackResult:
+    """≙ the Ok value of VitTrack::update: .success, .score, .bbox ([x, y, w, h])"""
+    __slots__ = ("success", "score", "bbox")
+
+    def __init__(self, c: CResult):
+        self.success = bool(c.success)
+        self.score = float(c.score)
+        self.bbox = [c.bbox.x, c.bbox.y, c.bbox.width, c.bbox.height]
+
+    def __repr__(self):
+        return f"TrackResult(success={self.success}, score={self.score:.4f}, bbox={self.bbox})"
+
+
+class NV12Frame:
+    """packed NV12 host buffer: Y plane then interleaved UV, stride == width
+    (the layout /root/reference/src/nv12_convert.rs:47-54 assumes)"""
+
+    def __init__(self, buf: np.ndarray, width: int, height: int):
+        self.buf = np.ascontiguousarray(buf, np.uint8).reshape(-1)
+        self.w, self.h = width, height
+        assert self.buf.size >= width * height + ((width + 1) & ~1) * ((height + 1) // 2)
+
+
+class VitTrack:
+    """≙ vit_tracker::VitTrack (src/tracker_context.rs:21,88,90,120)."""
+
+    def __init__(self, weights_path: str, device: int = 0, success_threshold: float = -1.0,
+                 use_graph: bool = True, max_w: int = 0, max_h: int = 0):
+        self._h = c_void_p()
+        cfg = make_config(success_threshold, use_graph, 1, max_w, max_h)
+        _check(lib().vt_create(weights_path.encode(), device, byref(cfg), byref(self._h)))
+
+    @staticmethod
+    def new(model_path: str, **kw) -> "VitTrack":
+        return VitTrack(model_path, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().vt_destroy(self._h)
+            self._h = c_void_p()
+
+    __del__ = close
+
+    def model_info(self) -> CModelInfo:
+        mi = CModelInfo()
+        _check(lib().vt_get_model_info(self._h, byref(mi)))
+        return mi
+
+    def as_group(self) -> "Group":
+        return Group._view(lib().vt_tracker_as_group(self._h), self)
+
+    def init(self, frame, bbox: BBox) -> None:
+        """frame: (H,W,3) uint8 RGB array (≙ ArrayView3<u8>) or NV12Frame. Like the reference's
+        call site (src/tracker_context.rs:88) the caller gets nothing back; errors raise."""
+        if isinstance(frame, NV12Frame):
+            y = frame.buf
+            uv = frame.buf[frame.w * frame.h:]
+            _check(lib().vt_init_nv12(self._h, _u8(y), _u8(uv), frame.w, frame.h, frame.w,
+                                      (frame.w + 1) & ~1, bbox._c()))
+        else:
+            a = np.ascontiguousarray(frame, np.uint8)
+            h, w, _ = a.shape
+            _check(lib().vt_init_rgb8(self._h, _u8(a), w, h, w * 3, bbox._c()))
+
+    def update(self, frame) -> TrackResult:
+        r = CResult()
+        if isinstance(frame, NV12Frame):
+            y = frame.buf
+            uv = frame.buf[frame.w * frame.h:]
+            _check(lib().vt_update_nv12(self._h, _u8(y), _u8(uv), frame.w, frame.h, frame.w,
+                                        (frame.w + 1) & ~1, byref(r)))
+        else:
+            a = np.ascontiguousarray(frame, np.uint8)
+            h, w, _ = a.shape
+            _check(lib().vt_update_rgb8(self._h, _u8(a), w, h, w * 3, byref(r)))
+        return TrackResult(r)
+
+    # device-resident frames (pointers into this GPU's HBM, e.g. torch tensors' data_ptr())
+    def init_nv12_device(self, d_y, d_uv, w, h, y_stride, uv_stride, bbox: BBox):
+        _check(lib().vt_init_nv12_device(self._h, d_y, d_uv, w, h, y_stride, uv_stride, bbox._c()))
+
+    def update_nv12_device(self, d_y, d_uv, w, h, y_stride, uv_stride) -> TrackResult:
+        r = CResult()
+        _check(lib().vt_update_nv12_device(self._h, d_y, d_uv, w, h, y_stride, uv_stride,
+                                           byref(r)))
+        return TrackResult(r)
+
+    def init_rgb8_device(self, d_rgb, w, h, stride, bbox: BBox):
+        _check(lib().vt_init_rgb8_device(self._h, d_rgb, w, h, stride, bbox._c()))
+
+    def update_rgb8_device(self, d_rgb, w, h, stride) -> TrackResult:
+        r = CResult()
+        _check(lib().vt_update_rgb8_device(self._h, d_rgb, w, h, stride, byref(r)))
+        return TrackResult(r)
+
+
+def frame_nv12(d_y, d_uv, w, h, y_stride=None, uv_stride=None) -> CFrame:
+    return CFrame(d_y, d_uv, w, h, y_stride or w, uv_stride or ((w + 1) & ~1), PIX_NV12, 0)
+
+
+def frame_rgb8(d_rgb, w, h, stride=None) -> CFrame:
+    return CFrame(d_rgb, None, w, h, stride or 3 * w, 0, PIX_RGB8, 0)
+
+
+class Group:
+    """B independent tracked streams batched on one GPU (vt_group_*)."""
+
+    def __init__(self, weights_path: str | None = None, n_streams: int = 1, device: int = 0,
+                 success_threshold: float = -1.0, use_graph: bool = True,
+                 device_blob: tuple[int, int] | None = None):
+        self._h = c_void_p()
+        self._owner = None
+        cfg = make_config(success_threshold, use_graph, n_streams)
+        if device_blob is not None:
+            ptr, nbytes = device_blob
+            _check(lib().vt_group_create_from_device_blob(ptr, nbytes, device, byref(cfg),
+                                                          byref(self._h)))
+        else:
+            _check(lib().vt_group_create(weights_path.encode(), device, byref(cfg),
+                                         byref(self._h)))
+        self._own = True
+
+    @classmethod
+    def _view(cls, handle, owner):
+        g = cls.__new__(cls)
+        g._h = c_void_p(handle)
+        g._owner = owner
+        g._own = False
+        return g
+
+    def close(self):
+        if getattr(self, "_own", False) and self._h.value:
+            lib().vt_group_destroy(self._h)
+        self._h = c_void_p()
+
+    __del__ = close
+
+    @property
+    def streams(self) -> int:
+        return lib().vt_group_streams(self._h)
+
+    def model_info(self) -> CModelInfo:
+        mi = CModelInfo()
+        _check(lib().vt_group_get_model_info(self._h, byref(mi)))
+        return mi
+
+    def hip_stream(self) -> int:
+        return lib().vt_group_hip_stream(self._h)
+
+    def init_device(self, stream: int, frame: CFrame, bbox: BBox):
+        _check(lib().vt_group_init_device(self._h, stream, byref(frame), bbox._c()))
+
+    @staticmethod
+    def _arr(frames):
+        arr = (CFrame * len(frames))(*frames)
+        return arr
+
+    def enqueue_device(self, frames):
+        arr = self._arr(frames)
+        _check(lib().vt_group_enqueue_device(self._h, arr, len(frames)))
+
+    def wait(self):
+        n = self.streams
+        out = (CResult * n)()
+        _check(lib().vt_group_wait(self._h, out, n))
+        return [TrackResult(r) for r in out]
+
+    def update_device(self, frames):
+        arr = self._arr(frames)
+        out = (CResult * len(frames))()
+        _check(lib().vt_group_update_device(self._h, arr, len(frames), out))
+        return [TrackResult(r) for r in out]
+
+    def profile_device(self, frames, iters=5):
+        arr = self._arr(frames)
+        out = (CKernelTime * 64)()
+        n = _check(lib().vt_group_profile_device(self._h, arr, len(frames), iters, out, 64))
+        return [dict(name=out[i].name.decode(), launches=out[i].launches,
+                     ms=float(out[i].ms_total), flops=out[i].flops, bytes=out[i].bytes)
+                for i in range(n)]
+
+    def enable_taps(self, on=True):
+        _check(lib().vt_group_enable_taps(self._h, 1 if on else 0))
+
+    def read_tensor(self, name: str, stream: int = 0) -> np.ndarray:
+        n = _check(lib().vt_group_read_tensor(self._h, stream, name.encode(), None, 0))
+        out = np.empty(n, np.float32)
+        _check(lib().vt_group_read_tensor(self._h, stream, name.encode(), _f32(out), n))
+        return out
+
+    def read_state(self, stream: int = 0) -> dict:
+        raw = self.read_tensor("state", stream)
+        i = raw.view(np.int32)
+        return dict(box=raw[0:4].copy(), geo=raw[4:8].copy(), frame_w=int(i[8]),
+                    frame_h=int(i[9]), initialized=int(i[10]), frames_done=int(i[11]),
+                    success_count=int(i[12]), last_idx=int(i[13]), last_fbox=raw[14:18].copy(),
+                    last_score=float(raw[18]))
+
+
+# ---- reference colour converter -------------------------------------------------------------
+
+def nv12_full_to_rgb(nv12_data: np.ndarray, width: int, height: int, device: int = 0):
+    """≙ nv12_full_to_rgb_parallel (src/nv12_convert.rs:46) on the GPU -> (H,W,3) uint8"""
+    buf = np.ascontiguousarray(nv12_data, np.uint8).reshape(-1)
+    out = np.empty((height, width, 3), np.uint8)
+    _check(lib().vt_nv12_to_rgb8(device, _u8(buf), buf.size, width, height, _u8(out)))
+    return out
+
+
+# ---- operator-level entry points (numerics tests) -------------------------------------------
+
+def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0):
+    a_bits = np.ascontiguousarray(a_bits, np.uint16)
+    w_bits = np.ascontiguousarray(w_bits, np.uint16)
+    M, K = a_bits.shape
+    N = w_bits.shape[0]
+    c = np.zeros((M, N), np.float32) if c_init is None else np.ascontiguousarray(c_init,
+                                                                                 np.float32).copy()
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    _check(lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
+                                 _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue))
+    return c
+
+
+def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0):
+    a_bits = np.ascontiguousarray(a_bits, np.uint16)
+    w_bits = np.ascontiguousarray(w_bits, np.uint16)
+    bias = np.ascontiguousarray(bias, np.float32)
+    npad = (tokens + 31) // 32 * 32
+    qk = np.empty((B * tokens, 2 * D), np.float32)
+    vt = np.empty((B * (D // 64), 64, npad), np.float32)
+    _check(lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),
+                                _f32(vt), B, tokens, D))
+    return qk, vt
+
+
+def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0):
+    q_bits, k_bits, v_bits = (np.ascontiguousarray(x, np.uint16) for x in (q_bits, k_bits, v_bits))
+    out = np.empty((B * N, H * 64), np.float32)
+    _check(lib().vt_op_attention_bf16(device, _u16(q_bits), _u16(k_bits), _u16(v_bits), _f32(out),
+                                      B, N, H))
+    return out
+
+
+def op_layernorm(x, gamma, beta, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    g = np.ascontiguousarray(gamma, np.float32)
+    b = np.ascontiguousarray(beta, np.float32)
+    y = np.empty_like(x)
+    _check(lib().vt_op_layernorm(device, _f32(x), _f32(g), _f32(b), _f32(y), x.shape[0],
+                                 x.shape[1]))
+    return y

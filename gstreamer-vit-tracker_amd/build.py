@@ -1,0 +1,90 @@
+"""Builds the in-tree shared libraries with hipcc / g++ (no cmake, no JIT cache):
+
+  gstreamer-vit-tracker_amd/libvittrack_hip.so   HIP kernels + C ABI (include/vittrack_hip.h),
+                                                 code object for gfx950 only
+  gstreamer-vit-tracker_amd/libvittrack_host.so  C++ mirror of the reference host logic
+                                                 (include/vittrack_host.h)
+
+hipcc cross-compiles gfx950 without a GPU. The .so files are git-ignored but travel to the GPU
+box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+OBJ = os.path.join(PKG, "build")
+LIB_HIP = os.path.join(PKG, "libvittrack_hip.so")
+LIB_HOST = os.path.join(PKG, "libvittrack_host.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "vt_engine.hip"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",
+             "-Wno-unused-function"]
+HOST_SOURCES = ["host_capi.cpp"]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build step failed: {cmd[0]} ... {cmd[-1]}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build_hip(force: bool = False, save_temps: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "vt_common.hpp"),
+               os.path.join(PKG, "..", "include", "vittrack_hip.h")]
+    objs, jobs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            cmd = [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]
+            if save_temps:
+                cmd += ["-save-temps=obj"]
+            jobs.append(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(LIB_HIP):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs)
+    return LIB_HIP
+
+
+def build_host(force: bool = False) -> str:
+    srcs = [os.path.join(HOST, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [
+        os.path.join(PKG, "..", "include", "vittrack_host.h"),
+        os.path.join(PKG, "..", "include", "vittrack_hip.h")]
+    if force or _newer(LIB_HOST, deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST] + srcs +
+             ["-ldl", "-lpthread"])
+    return LIB_HOST
+
+
+def build_all(force: bool = False):
+    return build_hip(force), build_host(force)
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_hip(force, save_temps="--save-temps" in sys.argv))
+    if os.path.exists(os.path.join(HOST, "host_capi.cpp")):
+        print(build_host(force))

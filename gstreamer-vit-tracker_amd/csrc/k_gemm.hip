@@ -1,0 +1,297 @@
+// k_gemm.hip — bf16 MFMA GEMM for gfx950: C[M,N] = A[M,K] · W[N,K]^T (+ fused epilogue).
+//
+// Every dense contraction of the tracker goes through this kernel: patch-embed, QKV, attention
+// output projection, MLP fc1/fc2, and the head's 1x1 / im2col'd 3x3 convolutions. Both operands
+// are K-contiguous ("A rows" and "W rows"), so one staging routine and one fragment reader serve
+// both.
+//
+// Structure (CDNA4):
+//   * 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN (128x128 or 64x64), BK = 64.
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
+//     instruction = 8 tile rows of 128 B); two LDS stages; the loads of K-tile t+1 are in flight
+//     while the MFMAs of tile t run; one barrier per K-tile.
+//   * LDS image: rows of 128 B (64 bf16); the 16-B chunk c of row r is stored at chunk
+//     c ^ ((r >> 1) & 7). LDS-DMA writes lane-linear, so the XOR is applied to the per-lane
+//     SOURCE address and again on the read (guide rule 21). With this swizzle the ds_read_b128
+//     of a 32-row MFMA operand is bank-conflict free for both 16-lane halves of each read group.
+//   * v_mfma_f32_32x32x16_bf16, f32 accumulate. The MFMA operand order is chosen per epilogue so
+//     that the store side is wide: f32 outputs keep the column on the lane (128 B contiguous per
+//     row per store), bf16 row-major outputs put the ROW on the lane so each lane owns 4
+//     consecutive columns per accumulator quad (one 8-B store).
+#include "vt_common.hpp"
+
+#define GEMM_BK 64
+#define ROW_BYTES 128
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile
+__device__ __forceinline__ int acc_row(int reg, int half) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+
+template <int BM, int BN, bool ROW_ON_LANE>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
+                                              f32x16_t (&acc)[BM / 64][BN / 64]) {
+    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
+    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+    constexpr int STAGE = (BM + BN) * ROW_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // per-lane source pointers for the LDS-DMA pieces this wave issues (rows fixed over K)
+    const bf16_t* asrc[BM / 32];
+    const bf16_t* bsrc[BN / 32];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+        const int row = (wave * (BM / 32) + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        asrc[j] = p.A + (size_t)gm * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) {
+        const int row = (wave * (BN / 32) + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        bsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j)
+            glds16(asrc[j] + kt * GEMM_BK, sA + (wave * (BM / 32) + j) * 8 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j)
+            glds16(bsrc[j] + kt * GEMM_BK, sB + (wave * (BN / 32) + j) * 8 * ROW_BYTES);
+    };
+
+    // fragment read offsets (bytes inside a stage), per k-step the chunk index changes by 2
+    int aoff[TM], boff[TN], aswz[TM], bswz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wr * WM + i * 32 + l31;
+        aoff[i] = row * ROW_BYTES;
+        aswz[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 32 + l31;
+        boff[j] = BM * ROW_BYTES + row * ROW_BYTES;
+        bswz[j] = (row >> 1) & 7;
+    }
+
+    const int nk = p.K / GEMM_BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // tile kt has landed (this wave's pieces) and every wave is done reading stage cur^1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* sbase = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af[TM], bfr[TN];
+            const int c = 2 * ks + half;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((c ^ aswz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((c ^ bswz[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (ROW_ON_LANE)  // D[n][m]: lane = m (row of C), registers = n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i],
+                                                                            acc[i][j], 0, 0, 0);
+                    else              // D[m][n]: lane = n (column of C), registers = m
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j],
+                                                                            acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = BM / 64, TN = BN / 64, WM = BM / 2, WN = BN / 2;
+    const int tiles_n = p.N / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM;
+    const int n0 = (blockIdx.x % tiles_n) * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
+        gemm_mainloop<BM, BN, false>(p, smem, m0, n0, acc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * WN + j * 32 + l31;
+                const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * WM + i * 32 + acc_row(r, half);
+                    if (m < p.M) {
+                        float* dst = p.Cf + (size_t)m * p.ldc + n;
+                        float v = acc[i][j][r] + bias;
+                        if constexpr (EPI == EPI_F32_POS)
+                            v += p.pos[(size_t)(m % p.pos_rows) * p.ldc + n];
+                        if constexpr (EPI == EPI_RESID) v += *dst;
+                        *dst = v;
+                    }
+                }
+            }
+    } else if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
+        gemm_mainloop<BM, BN, true>(p, smem, m0, n0, acc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * WM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * q + e] + p.bias[n + e];
+                        v[e] = (EPI == EPI_GELU_BF16) ? gelu_erf(x) : fmaxf(x, 0.0f);
+                    }
+                    if (m < p.M) {
+                        uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldcb + n) = pk;
+                    }
+                }
+        }
+    } else {  // EPI_QKV
+        const int D = p.D;
+        if (n0 < 2 * D) {
+            // q (scaled by 1/8 = 1/sqrt(64), exact in bf16) and k: row-major [M][2D]
+            gemm_mainloop<BM, BN, true>(p, smem, m0, n0, acc);
+            const float sc = (n0 < D) ? 0.125f : 1.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wr * WM + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * half;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (acc[i][j][4 * q + e] + p.bias[n + e]) * sc;
+                        if (m < p.M) {
+                            uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]),
+                                                  pack_bf16x2(v[2], v[3]));
+                            *reinterpret_cast<uint2*>(p.qk + (size_t)m * (2 * D) + n) = pk;
+                        }
+                    }
+            }
+        } else {
+            // v: transposed per head, Vt[b][h][d][t] with t contiguous (npad per row), so the
+            // attention kernel reads 4 consecutive keys of one d with one 8-B load
+            gemm_mainloop<BM, BN, false>(p, smem, m0, n0, acc);
+            const int heads = D >> 6;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wc * WN + j * 32 + l31;
+                    const float bias = p.bias[n];
+                    const int nv = n - 2 * D, hh = nv >> 6, d = nv & 63;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = m0 + wr * WM + i * 32 + 8 * q + 4 * half;
+                        if (m < p.M) {
+                            const int b = m / p.tokens, t = m % p.tokens;
+                            uint2 pk = make_uint2(
+                                pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
+                                pack_bf16x2(acc[i][j][4 * q + 2] + bias,
+                                            acc[i][j][4 * q + 3] + bias));
+                            bf16_t* dst = p.vt + ((size_t)(b * heads + hh) * 64 + d) * p.npad + t;
+                            *reinterpret_cast<uint2*>(dst) = pk;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI>
+static hipError_t prepare_cfg() {
+    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+template <int EPI>
+static hipError_t prepare_epi() {
+    hipError_t e = prepare_cfg<128, 128, EPI>();
+    return e != hipSuccess ? e : prepare_cfg<64, 64, EPI>();
+}
+
+// Raise the dynamic-LDS limit of every instantiation once per device, outside any stream capture.
+hipError_t gemm_prepare() {
+    hipError_t e;
+    if ((e = prepare_epi<EPI_F32_POS>()) != hipSuccess) return e;
+    if ((e = prepare_epi<EPI_RESID>()) != hipSuccess) return e;
+    if ((e = prepare_epi<EPI_GELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_epi<EPI_RELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_epi<EPI_QKV>()) != hipSuccess) return e;
+    return prepare_epi<EPI_F32>();
+}
+
+template <int BM, int BN, int EPI>
+static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_epi(const GemmArgs& a, hipStream_t st) {
+    // 128x128 tiles when they alone fill the 256 CUs (or N forces it), else 64x64 for more blocks
+    const long big = (long)((a.M + 127) / 128) * (a.N / 128);
+    if ((a.N % 128 == 0) && big >= 192) return launch_cfg<128, 128, EPI>(a, st);
+    return launch_cfg<64, 64, EPI>(a, st);
+}
+
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {
+    if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
+    if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
+        return hipErrorInvalidValue;
+    switch (epilogue) {
+        case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, st);
+        case EPI_RESID: return launch_epi<EPI_RESID>(a, st);
+        case EPI_GELU_BF16: return launch_epi<EPI_GELU_BF16>(a, st);
+        case EPI_RELU_BF16: return launch_epi<EPI_RELU_BF16>(a, st);
+        case EPI_QKV: return launch_epi<EPI_QKV>(a, st);
+        case EPI_F32: return launch_epi<EPI_F32>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}

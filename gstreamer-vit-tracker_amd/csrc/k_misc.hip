@@ -1,0 +1,204 @@
+// k_misc.hip — LayerNorm, head im2col, and the on-device box decode for gfx950.
+#include "vt_common.hpp"
+
+// ---- LayerNorm: one wave per row, row kept in registers, two-pass variance -----------------------
+// f32 residual stream in, bf16 GEMM operand out. NCH = D / 128 float2 chunks per lane.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ y, int rows, int D,
+                                                        int group, int in_stride, int in_off,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const size_t in_row = (size_t)(r / group) * in_stride + in_off + (r % group);
+    const float2* xr = reinterpret_cast<const float2*>(x + in_row * D);
+    float2 v[NCH];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        v[j] = xr[lane + 64 * j];
+        sum += v[j].x + v[j].y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        v[j].x -= mean; v[j].y -= mean;
+        sq += v[j].x * v[j].x + v[j].y * v[j].y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+    const float2* g2 = reinterpret_cast<const float2*>(gamma);
+    const float2* b2 = reinterpret_cast<const float2*>(beta);
+    uint32_t* yr = reinterpret_cast<uint32_t*>(y + (size_t)r * D);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const float2 g = g2[lane + 64 * j], b = b2[lane + 64 * j];
+        yr[lane + 64 * j] = pack_bf16x2((v[j].x * rstd) * g.x + b.x, (v[j].y * rstd) * g.y + b.y);
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
+                            int rows, int D, int group, int in_stride, int in_off, float eps,
+                            hipStream_t st) {
+    if (rows <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(n)                                                                              \
+    case n:                                                                                     \
+        hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, gamma, beta, y, rows, D, \
+                           group, in_stride, in_off, eps);                                      \
+        break;
+    switch (D / 128) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(10) LN_CASE(12)
+        default: return hipErrorInvalidValue;
+    }
+#undef LN_CASE
+    return hipGetLastError();
+}
+
+// ---- im2col for the head's 3x3 convolutions (zero padding), 16 B per lane -----------------------
+// t [B*grid*grid][C] -> col [B*grid*grid][9*C], column (ky*3+kx)*C + c
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict__ t,
+                                                        bf16_t* __restrict__ col, int B, int grid,
+                                                        int C) {
+    const int chunks = C / 8;
+    const long total = (long)B * grid * grid * 9 * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        long rest = i / chunks;
+        const int tap = (int)(rest % 9);
+        rest /= 9;
+        const int cell = (int)(rest % (grid * grid));
+        const int b = (int)(rest / (grid * grid));
+        const int y = cell / grid + tap / 3 - 1, x = cell % grid + tap % 3 - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y >= 0 && y < grid && x >= 0 && x < grid)
+            v = *reinterpret_cast<const uint4*>(t + ((size_t)b * grid * grid + y * grid + x) * C +
+                                                ch * 8);
+        *reinterpret_cast<uint4*>(col + ((size_t)b * grid * grid + cell) * 9 * C + tap * C +
+                                  ch * 8) = v;
+    }
+}
+
+hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C, hipStream_t st) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)B * grid * grid * 9 * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks), dim3(256), 0, st, t, col, B, grid, C);
+    return hipGetLastError();
+}
+
+// ---- last head layer (C -> 5 logits, f32) + score window + argmax + box decode --------------------
+// One 256-thread block per stream. Writes vt_result and the stream state the next frame's
+// preprocessing reads. Same float op order as vto_decode (oracle/vt_oracle.c).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    __shared__ float s_best[256];
+    __shared__ int s_idx[256];
+    __shared__ float s_logit[256][5];  // logits of each thread's own best cell
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ns = a.ns, C = a.C;
+    float best = -1.0f;
+    int bidx = 0x7fffffff;
+    float bo[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = tid; i < ns; i += 256) {
+        const bf16_t* row = a.t3 + ((size_t)b * ns + i) * C;
+        float o[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] = 0.0f;
+        for (int c = 0; c < C; c += 8) {
+            const uint4 pk = *reinterpret_cast<const uint4*>(row + c);
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u)
+                                                        : (w[e >> 1] << 16));
+#pragma unroll
+                for (int k = 0; k < 5; ++k) o[k] += t * a.w4[k * C + c + e];
+            }
+        }
+        float* ho = a.head_out + ((size_t)b * ns + i) * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { o[k] += a.b4[k]; ho[k] = o[k]; }
+        ho[5] = ho[6] = ho[7] = 0.0f;
+        const float resp = sigmoidf_(o[0]) * a.hann[i];
+        if (resp > best) {  // ascending i per thread: first max kept
+            best = resp; bidx = i;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) bo[k] = o[k];
+        }
+    }
+    s_best[tid] = best;
+    s_idx[tid] = bidx;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_logit[tid][k] = bo[k];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            const float ob = s_best[tid + off];
+            const int oi = s_idx[tid + off];
+            if (ob > s_best[tid] || (ob == s_best[tid] && oi < s_idx[tid])) {
+                s_best[tid] = ob;
+                s_idx[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    StreamState& s = a.states[b];
+    const int idx = s_idx[0];
+    const float* o = s_logit[idx & 255];  // cell i is handled by thread i % 256
+    const float score = sigmoidf_(o[0]);
+    const float offx = sigmoidf_(o[1]), offy = sigmoidf_(o[2]);
+    const float wn = sigmoidf_(o[3]), hn = sigmoidf_(o[4]);
+    const int grid = a.grid;
+    const int ix = idx % grid, iy = idx / grid;
+    const float side = s.geo[3];
+    const float cxn = ((float)ix + offx) / (float)grid;
+    const float cyn = ((float)iy + offy) / (float)grid;
+    const float cx = (s.geo[0] + 0.5f) + cxn * side;
+    const float cy = (s.geo[1] + 0.5f) + cyn * side;
+    float bw = wn * side, bh = hn * side;
+    float x1 = cx - 0.5f * bw, y1 = cy - 0.5f * bh;
+    float x2 = x1 + bw, y2 = y1 + bh;
+    const float margin = 10.0f;
+    const float W = (float)s.frame_w, Hh = (float)s.frame_h;
+    x1 = fminf(fmaxf(0.0f, x1), W - margin);
+    y1 = fminf(fmaxf(0.0f, y1), Hh - margin);
+    x2 = fminf(fmaxf(margin, x2), W);
+    y2 = fminf(fmaxf(margin, y2), Hh);
+    bw = fmaxf(margin, x2 - x1);
+    bh = fmaxf(margin, y2 - y1);
+    const int success = (score >= a.success_threshold) ? 1 : 0;
+    vt_result r;
+    r.success = success;
+    r.score = score;
+    r.bbox.x = (int32_t)floorf(x1 + 0.5f);
+    r.bbox.y = (int32_t)floorf(y1 + 0.5f);
+    r.bbox.width = (int32_t)floorf(bw + 0.5f);
+    r.bbox.height = (int32_t)floorf(bh + 0.5f);
+    a.results[b] = r;
+    s.last_fbox[0] = x1; s.last_fbox[1] = y1; s.last_fbox[2] = bw; s.last_fbox[3] = bh;
+    s.last_score = score;
+    s.last_idx = idx;
+    s.frames_done += 1;
+    if (success) {
+        s.success_count += 1;
+        s.box[0] = x1; s.box[1] = y1; s.box[2] = bw; s.box[3] = bh;
+    }
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
+    if (a.C % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

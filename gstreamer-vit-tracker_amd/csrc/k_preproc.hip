@@ -1,0 +1,159 @@
+// k_preproc.hip — pixel stages of the hot path for gfx950.
+//
+//  * nv12_to_rgb8_kernel: the reference's whole-frame converter
+//    (/root/reference/src/nv12_convert.rs:46-169) as one HBM-bound pass: 1.5 B read + 3 B written
+//    per pixel, 4 pixels per lane, integer arithmetic identical to the reference (same constants,
+//    arithmetic >> 8, clamp).
+//  * preproc_kernel: what VitTrack::init / update do first (call sites
+//    /root/reference/src/tracker_context.rs:88,90,120): crop a window around the last box, resize it
+//    bilinearly, normalise, and emit it directly as the bf16 patch matrix the patch-embed GEMM reads
+//    (row = token, column = c*p*p + py*p + px). Only the crop window is ever converted from NV12 —
+//    the reference converts the whole 1080p frame (src/pipeline.rs:105) although the tracker
+//    consumes one window. Every sampled NV12 pixel goes through the reference's integer formulas.
+//
+// Float op order is fixed (this file is compiled with -ffp-contract=off and correctly rounded
+// sqrt/div) and identical to oracle/vt_oracle.c, so the outputs agree bit for bit.
+#include "vt_common.hpp"
+
+// /root/reference/src/nv12_convert.rs:24-29 (table entries) and :124-131 (per pixel)
+__device__ __forceinline__ void yuv_to_rgb(int y, int u, int v, int& r, int& g, int& b) {
+    const int yv = 298 * (y - 16);
+    r = (yv + 409 * (v - 128) + 128) >> 8;
+    g = (yv - 100 * (u - 128) - 208 * (v - 128) + 128) >> 8;
+    b = (yv + 516 * (u - 128) + 128) >> 8;
+    r = min(max(r, 0), 255);
+    g = min(max(g, 0), 255);
+    b = min(max(b, 0), 255);
+}
+
+// One lane converts 4 horizontally adjacent pixels (two UV pairs). Packed NV12, stride == width
+// (src/nv12_convert.rs:53-54,105-106).
+__global__ __launch_bounds__(256) void nv12_to_rgb8_kernel(const uint8_t* __restrict__ nv12, int w,
+                                                           int h, uint8_t* __restrict__ rgb) {
+    const int groups_per_row = (w + 3) >> 2;
+    const long total = (long)groups_per_row * h;
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)w * h;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(g / groups_per_row);
+        const int col0 = (int)(g % groups_per_row) * 4;
+        const size_t yrow = (size_t)row * w;
+        const size_t uvrow = (size_t)(row >> 1) * w;
+        if (col0 + 3 < w && ((w & 3) == 0)) {
+            // aligned fast path: 4 B of Y, 4 B of UV, 12 B out
+            const uint32_t y4 = *reinterpret_cast<const uint32_t*>(yp + yrow + col0);
+            const uint32_t uv4 = *reinterpret_cast<const uint32_t*>(uvp + uvrow + col0);
+            int r[4], gg[4], b[4];
+            yuv_to_rgb(y4 & 255, uv4 & 255, (uv4 >> 8) & 255, r[0], gg[0], b[0]);
+            yuv_to_rgb((y4 >> 8) & 255, uv4 & 255, (uv4 >> 8) & 255, r[1], gg[1], b[1]);
+            yuv_to_rgb((y4 >> 16) & 255, (uv4 >> 16) & 255, uv4 >> 24, r[2], gg[2], b[2]);
+            yuv_to_rgb(y4 >> 24, (uv4 >> 16) & 255, uv4 >> 24, r[3], gg[3], b[3]);
+            uint32_t* o = reinterpret_cast<uint32_t*>(rgb + (yrow + col0) * 3);
+            o[0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+            o[1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+            o[2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+        } else {
+            for (int c = col0; c < min(col0 + 4, w); ++c) {
+                // UV pair of column (c & ~1): src/nv12_convert.rs:111-113 and the odd tail :152
+                const int u = uvp[uvrow + (c & ~1)], v = uvp[uvrow + (c & ~1) + 1];
+                int r, gg, b;
+                yuv_to_rgb(yp[yrow + c], u, v, r, gg, b);
+                uint8_t* o = rgb + (yrow + c) * 3;
+                o[0] = (uint8_t)r; o[1] = (uint8_t)gg; o[2] = (uint8_t)b;
+            }
+        }
+    }
+}
+
+hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st) {
+    const long total = (long)((w + 3) >> 2) * h;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nv12_to_rgb8_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
+    return hipGetLastError();
+}
+
+// frame pixel (px,py) as float RGB; outside the frame -> 0 (zero padding)
+__device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, float* rgb) {
+    if (px < 0 || py < 0 || px >= f.w || py >= f.h) {
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        return;
+    }
+    int r, g, b;
+    if (f.fmt == VT_PIX_RGB8) {
+        const uint8_t* p = f.p0 + (size_t)py * f.s0 + (size_t)px * 3;
+        r = p[0]; g = p[1]; b = p[2];
+    } else {
+        const int y = f.p0[(size_t)py * f.s0 + px];
+        const uint8_t* uv = f.p1 + (size_t)(py >> 1) * f.s1 + (px & ~1);
+        yuv_to_rgb(y, uv[0], uv[1], r, g, b);
+    }
+    rgb[0] = (float)r; rgb[1] = (float)g; rgb[2] = (float)b;
+}
+
+// grid: (ceil(size*size/256), nb); one lane per output pixel, 3 channels each.
+__global__ __launch_bounds__(256) void preproc_kernel(const FrameDesc* __restrict__ frames,
+                                                      StreamState* __restrict__ states,
+                                                      bf16_t* __restrict__ patches, int b0,
+                                                      int size, int patch, int kpad, int ntok,
+                                                      int row_off, float factor, float na0,
+                                                      float na1, float na2, float nb0, float nb1,
+                                                      float nb2, int is_template) {
+    const int b = b0 + blockIdx.y;
+    const FrameDesc f = frames[b];
+    StreamState& s = states[b];
+    // crop geometry — same operations, same order as vto_crop_geometry (oracle/vt_oracle.c)
+    const float bx = s.box[0], by = s.box[1], bw = s.box[2], bh = s.box[3];
+    const float area = bw * bh;
+    const float side = factor * sqrtf(area);
+    const float scale = side / (float)size;
+    const float cx = bx + 0.5f * bw;
+    const float cy = by + 0.5f * bh;
+    const float half = 0.5f * side;
+    const float x0m = (cx - half) - 0.5f;
+    const float y0m = (cy - half) - 0.5f;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix == 0 && !is_template) {
+        s.geo[0] = x0m; s.geo[1] = y0m; s.geo[2] = scale; s.geo[3] = side;
+        s.frame_w = f.w; s.frame_h = f.h;
+    }
+    if (pix >= size * size) return;
+    const int oy = pix / size, ox = pix % size;
+    const float fy = ((float)oy + 0.5f) * scale + y0m;
+    const float fx = ((float)ox + 0.5f) * scale + x0m;
+    const float fy0 = floorf(fy), fx0 = floorf(fx);
+    const float wy = fy - fy0, wx = fx - fx0;
+    const int iy = (int)fy0, ix = (int)fx0;
+    float p00[3], p01[3], p10[3], p11[3];
+    fetch_rgb(f, ix, iy, p00);
+    fetch_rgb(f, ix + 1, iy, p01);
+    fetch_rgb(f, ix, iy + 1, p10);
+    fetch_rgb(f, ix + 1, iy + 1, p11);
+    const int grid = size / patch;
+    const int token = (oy / patch) * grid + (ox / patch);
+    const int kin = (oy % patch) * patch + (ox % patch);
+    bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
+    const float na[3] = {na0, na1, na2}, nb[3] = {nb0, nb1, nb2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = p00[c] + wx * (p01[c] - p00[c]);
+        const float bot = p10[c] + wx * (p11[c] - p10[c]);
+        const float v = top + wy * (bot - top);
+        const float o = v * na[c] + nb[c];
+        row[c * patch * patch + kin] = f32_to_bf16(o);
+    }
+}
+
+hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
+                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st) {
+    const int size = is_template ? d.T : d.S;
+    const int row_off = is_template ? 0 : d.nt;
+    const float factor = is_template ? 2.0f : 4.0f;
+    dim3 grid((size * size + 255) / 256, nb);
+    hipLaunchKernelGGL(preproc_kernel, grid, dim3(256), 0, st, frames, states, patches, b0, size,
+                       d.patch, d.kpad, d.ntok, row_off, factor, d.norm_a[0], d.norm_a[1],
+                       d.norm_a[2], d.norm_b[0], d.norm_b[1], d.norm_b[2], is_template ? 1 : 0);
+    return hipGetLastError();
+}

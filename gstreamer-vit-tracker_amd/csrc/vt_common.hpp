@@ -1,0 +1,113 @@
+// vt_common.hpp — types shared by the host engine and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vittrack_hip.h"
+
+typedef uint16_t bf16_t;  // bfloat16 bit pattern
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// one device-resident input frame (mirrors vt_frame, 64-bit pointers)
+struct FrameDesc {
+    const uint8_t* p0;  // RGB8 packed pixels or NV12 Y plane
+    const uint8_t* p1;  // NV12 interleaved UV plane
+    int32_t w, h, s0, s1, fmt, pad;
+};
+
+// per tracked stream, lives in HBM; the decode kernel of frame t writes what the preprocessing
+// kernel of frame t+1 reads, so a stream of updates never needs the host in between.
+struct StreamState {
+    float box[4];        // last accepted box, frame pixels: x, y, w, h (top-left + size)
+    float geo[4];        // search-crop geometry of the running frame: x0m, y0m, scale, side
+    int32_t frame_w, frame_h;
+    int32_t initialized;
+    int32_t frames_done;     // updates completed since init
+    int32_t success_count;   // of which result.success
+    int32_t last_idx;        // argmax cell of the last update
+    float last_fbox[4];      // unrounded clipped box of the last update
+    float last_score;
+    int32_t pad[3];
+};
+
+struct ModelDims {
+    int patch, T, S, D, H, L, mlp, C, kpad;
+    int gt, gs, nt, ns, ntok;   // grids and token counts
+    int npad;                   // ntok rounded up to 32 (attention key padding)
+    float norm_a[3], norm_b[3];
+    float success_threshold, ln_eps;
+};
+
+// ---- kernel launchers (each enqueues on `st`; no allocation, no synchronisation) -------------
+
+enum GemmEpilogue {
+    EPI_F32_POS = 0,   // C f32 = acc + bias + pos[m % pos_rows]      (patch embed)
+    EPI_RESID = 1,     // C f32 += acc + bias                          (proj, fc2)
+    EPI_GELU_BF16 = 2, // Cb bf16 = gelu(acc + bias)                   (fc1)
+    EPI_RELU_BF16 = 3, // Cb bf16 = relu(acc + bias)                   (head convs)
+    EPI_QKV = 4,       // q*0.125,k -> qk[M][2D] bf16; v -> Vt[b][h][64][npad]
+    EPI_F32 = 5        // C f32 = acc + bias                           (operator tests)
+};
+
+struct GemmArgs {
+    const bf16_t* A; int lda;     // [M][K] row-major bf16
+    const bf16_t* W; int ldw;     // [N][K] row-major bf16 (one output feature per row)
+    const float* bias;            // [N]
+    int M, N, K;
+    float* Cf; int ldc;           // f32 output / residual stream
+    bf16_t* Cb; int ldcb;         // bf16 output
+    const float* pos; int pos_rows;
+    bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
+};
+
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);
+hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
+
+// y[r] (bf16) = LN(x[in_row(r)]) ; in_row(r) = (r / group) * in_stride + in_off + r % group
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
+                            int rows, int D, int group, int in_stride, int in_off, float eps,
+                            hipStream_t st);
+
+// out[M][D] bf16 = softmax(q k^T) v, q/k rows in qk[M][2D], v transposed in vt[B*H][64][npad]
+hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
+                            int H, int npad, hipStream_t st);
+
+// crop + bilinear + normalise -> patch rows; one launch covers streams [b0, b0+nb)
+hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
+                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st);
+
+hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st);
+
+hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C, hipStream_t st);
+
+struct DecodeArgs {
+    const bf16_t* t3;       // [B*ns][C]
+    const float* w4;        // [8][C]
+    const float* b4;        // [8]
+    const float* hann;      // [ns]
+    float* head_out;        // [B*ns][8]
+    StreamState* states;    // [B]
+    vt_result* results;     // [B] (device)
+    int B, ns, grid, C;
+    float success_threshold;
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t st);
+
+// ---- small device helpers ---------------------------------------------------------------------
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) {
+    return __uint_as_float(((uint32_t)b) << 16);
+}
+// round to nearest even; NaN kept a NaN (plain cast path is not used so that host/device agree)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}

@@ -1,0 +1,1115 @@
+// vt_engine.hip — host side of libvittrack_hip.so: weight blob, per-GPU buffers, the per-frame
+// launch plan (eager or one hipGraph replay), and the extern "C" ABI of include/vittrack_hip.h.
+//
+// One Engine = B independent tracked streams on one GPU. Everything a frame needs stays in HBM:
+// the decode kernel of frame t writes the box that the preprocessing kernel of frame t+1 reads, so
+// a stream of updates is a pure device-side chain; the host only supplies frame pointers and
+// collects 24 B of result per stream.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vt_common.hpp"
+
+// ---- error plumbing ------------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return set_err(VT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                            \
+    } while (0)
+
+// ---- weight blob ---------------------------------------------------------------------------------
+
+static const char kMagic[8] = {'V', 'T', 'W', 'B', '0', '0', '0', '1'};
+static const size_t kHeaderBytes = 256, kEntryBytes = 64;
+
+struct BlobEntry {
+    char name[32];
+    uint32_t dtype, rows, cols, pad;
+    uint64_t offset, nbytes;
+};
+static_assert(sizeof(BlobEntry) == 64, "blob entry layout");
+
+struct TensorRef {
+    const void* ptr = nullptr;
+    uint32_t dtype = 0, rows = 0, cols = 0;
+};
+
+struct LayerW {
+    const float *ln1_g, *ln1_b, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
+    const bf16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+
+struct KernelStat {
+    std::string name;
+    int launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+struct Profiler {
+    struct Rec { hipEvent_t a, b; int fam; };
+    std::vector<Rec> recs;
+    std::vector<KernelStat> fams;
+    int family(const std::string& n) {
+        for (size_t i = 0; i < fams.size(); ++i)
+            if (fams[i].name == n) return (int)i;
+        KernelStat k;
+        k.name = n;
+        fams.push_back(k);
+        return (int)fams.size() - 1;
+    }
+};
+
+const char* g_last_gemm_name = "";  // set by launch_gemm_named below
+
+static const char* gemm_name(int epi, int M, int N) {
+    static const char* tags[] = {"f32pos", "resid", "gelu", "relu", "qkv", "f32"};
+    const long big = (long)((M + 127) / 128) * (N / 128);
+    const bool b128 = (N % 128 == 0) && big >= 192;
+    static thread_local char buf[64];
+    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s", tags[epi], b128 ? "128x128" : "64x64");
+    return buf;
+}
+
+struct Engine {
+    int device = 0, B = 1;
+    bool use_graph = true, taps = false;
+    ModelDims d{};
+    hipStream_t stream = nullptr;
+    // weights
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    std::map<std::string, TensorRef> tens;
+    std::vector<LayerW> layers;
+    // activations
+    bf16_t *d_patches = nullptr, *d_ln = nullptr, *d_qk = nullptr, *d_vt = nullptr,
+           *d_attn = nullptr, *d_mlp = nullptr, *d_feat = nullptr, *d_ta = nullptr,
+           *d_tb = nullptr, *d_col = nullptr;
+    float *d_x = nullptr, *d_headout = nullptr, *d_taps = nullptr;
+    StreamState* d_states = nullptr;
+    FrameDesc* d_frames = nullptr;
+    vt_result* d_results = nullptr;
+    // pinned host
+    static const int RING = 8;
+    FrameDesc* h_frames = nullptr;  // [RING][B]
+    hipEvent_t ring_ev[RING]{};
+    int ring_pos = 0;
+    vt_result* h_results = nullptr;
+    StreamState* h_state = nullptr;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // host-pointer staging (single-stream API)
+    uint8_t* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    int max_w = 3840, max_h = 2160;
+    float success_threshold = 0.2f;
+    std::vector<int> h_initialized;
+
+    ~Engine() { destroy(); }
+    void destroy();
+    int load_blob_host(const std::vector<uint8_t>& blob);
+    int load_blob_device(const void* d_src, size_t bytes);
+    int index_blob(const uint8_t* host_copy, size_t bytes);
+    int alloc_buffers();
+    int run_pass(Profiler* prof);
+    int capture_graph();
+    int enqueue(const vt_frame* frames, int n);
+    int wait(vt_result* out, int n);
+    int init_stream(int b, const vt_frame* f, vt_bbox box);
+    const TensorRef* find(const std::string& n) const {
+        auto it = tens.find(n);
+        return it == tens.end() ? nullptr : &it->second;
+    }
+    double flops_encoder() const;
+    double flops_head() const;
+};
+
+void Engine::destroy() {
+    if (!stream && !d_blob) return;
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    void* devp[] = {d_blob, d_patches, d_ln, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_col,
+                    d_x, d_headout, d_taps, d_states, d_frames, d_results, d_stage};
+    for (void* p : devp)
+        if (p) (void)hipFree(p);
+    if (h_frames) (void)hipHostFree(h_frames);
+    if (h_results) (void)hipHostFree(h_results);
+    if (h_state) (void)hipHostFree(h_state);
+    for (int i = 0; i < RING; ++i)
+        if (ring_ev[i]) (void)hipEventDestroy(ring_ev[i]);
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    d_blob = nullptr;
+    graph = nullptr;
+    graph_exec = nullptr;
+}
+
+int Engine::index_blob(const uint8_t* hc, size_t bytes) {
+    if (bytes < kHeaderBytes || memcmp(hc, kMagic, 8) != 0)
+        return set_err(VT_ERR_FORMAT, "weight blob: bad magic or truncated header");
+    int32_t ints[20];
+    float fl[8];
+    memcpy(ints, hc + 8, sizeof(ints));
+    memcpy(fl, hc + 8 + 80, sizeof(fl));
+    if (ints[0] != 1) return set_err(VT_ERR_FORMAT, "weight blob: unsupported version %d", ints[0]);
+    d.patch = ints[1]; d.T = ints[2]; d.S = ints[3]; d.D = ints[4]; d.H = ints[5]; d.L = ints[6];
+    d.mlp = ints[7]; d.C = ints[8]; d.kpad = ints[9];
+    const int n_tensors = ints[10];
+    for (int i = 0; i < 3; ++i) { d.norm_a[i] = fl[i]; d.norm_b[i] = fl[3 + i]; }
+    d.success_threshold = fl[6];
+    d.ln_eps = fl[7];
+    if (d.patch <= 0 || d.T <= 0 || d.S <= 0 || d.T % d.patch || d.S % d.patch)
+        return set_err(VT_ERR_FORMAT, "weight blob: template/search not multiples of patch");
+    d.gt = d.T / d.patch; d.gs = d.S / d.patch;
+    d.nt = d.gt * d.gt; d.ns = d.gs * d.gs; d.ntok = d.nt + d.ns;
+    d.npad = (d.ntok + 31) / 32 * 32;
+    if (d.D % 128 || d.H != d.D / 64 || d.mlp % 64 || d.C % 64 || d.kpad % 64 ||
+        d.kpad < 3 * d.patch * d.patch || (d.ntok & 3) || (d.ns & 3) || d.L <= 0 || d.D > 1536)
+        return set_err(VT_ERR_FORMAT, "weight blob: unsupported model shape (D=%d H=%d mlp=%d C=%d "
+                       "kpad=%d tokens=%d)", d.D, d.H, d.mlp, d.C, d.kpad, d.ntok);
+    if (n_tensors <= 0 || kHeaderBytes + (size_t)n_tensors * kEntryBytes > bytes)
+        return set_err(VT_ERR_FORMAT, "weight blob: tensor table out of range");
+    tens.clear();
+    for (int i = 0; i < n_tensors; ++i) {
+        BlobEntry e;
+        memcpy(&e, hc + kHeaderBytes + (size_t)i * kEntryBytes, sizeof(e));
+        e.name[31] = 0;
+        const size_t esz = e.dtype == 1 ? 2 : 4;
+        if (e.dtype > 1 || e.offset % 16 || e.offset + e.nbytes > bytes ||
+            e.nbytes != (uint64_t)e.rows * e.cols * esz)
+            return set_err(VT_ERR_FORMAT, "weight blob: tensor '%s' malformed", e.name);
+        TensorRef r;
+        r.ptr = d_blob + e.offset;
+        r.dtype = e.dtype; r.rows = e.rows; r.cols = e.cols;
+        tens[e.name] = r;
+    }
+    auto need = [&](const std::string& n, uint32_t dt, uint32_t rows, uint32_t cols) -> const void* {
+        const TensorRef* t = find(n);
+        if (!t || t->dtype != dt || t->rows != rows || t->cols != cols) {
+            set_err(VT_ERR_FORMAT, "weight blob: tensor '%s' missing or wrong shape", n.c_str());
+            return nullptr;
+        }
+        return t->ptr;
+    };
+    const uint32_t D = d.D, C = d.C;
+    if (!need("patch_w", 1, D, d.kpad) || !need("patch_b", 0, 1, D) || !need("pos", 0, d.ntok, D) ||
+        !need("norm_g", 0, 1, D) || !need("norm_b", 0, 1, D) || !need("head.w0", 1, C, D) ||
+        !need("head.b0", 0, 1, C) || !need("head.w1", 1, C, 9 * C) || !need("head.b1", 0, 1, C) ||
+        !need("head.w2", 1, C, 9 * C) || !need("head.b2", 0, 1, C) ||
+        !need("head.w3", 1, C, 9 * C) || !need("head.b3", 0, 1, C) || !need("head.w4", 0, 8, C) ||
+        !need("head.b4", 0, 1, 8) || !need("hann", 0, 1, d.ns))
+        return VT_ERR_FORMAT;
+    layers.resize(d.L);
+    for (int l = 0; l < d.L; ++l) {
+        const std::string p = "l" + std::to_string(l) + ".";
+        LayerW& w = layers[l];
+        w.ln1_g = (const float*)need(p + "ln1_g", 0, 1, D);
+        w.ln1_b = (const float*)need(p + "ln1_b", 0, 1, D);
+        w.qkv_w = (const bf16_t*)need(p + "qkv_w", 1, 3 * D, D);
+        w.qkv_b = (const float*)need(p + "qkv_b", 0, 1, 3 * D);
+        w.proj_w = (const bf16_t*)need(p + "proj_w", 1, D, D);
+        w.proj_b = (const float*)need(p + "proj_b", 0, 1, D);
+        w.ln2_g = (const float*)need(p + "ln2_g", 0, 1, D);
+        w.ln2_b = (const float*)need(p + "ln2_b", 0, 1, D);
+        w.fc1_w = (const bf16_t*)need(p + "fc1_w", 1, d.mlp, D);
+        w.fc1_b = (const float*)need(p + "fc1_b", 0, 1, d.mlp);
+        w.fc2_w = (const bf16_t*)need(p + "fc2_w", 1, D, d.mlp);
+        w.fc2_b = (const float*)need(p + "fc2_b", 0, 1, D);
+        if (!w.ln1_g || !w.ln1_b || !w.qkv_w || !w.qkv_b || !w.proj_w || !w.proj_b || !w.ln2_g ||
+            !w.ln2_b || !w.fc1_w || !w.fc1_b || !w.fc2_w || !w.fc2_b)
+            return VT_ERR_FORMAT;
+    }
+    return VT_OK;
+}
+
+int Engine::load_blob_host(const std::vector<uint8_t>& blob) {
+    blob_bytes = blob.size();
+    HIPCHK(hipMalloc((void**)&d_blob, blob_bytes));
+    HIPCHK(hipMemcpy(d_blob, blob.data(), blob_bytes, hipMemcpyHostToDevice));
+    return index_blob(blob.data(), blob_bytes);
+}
+
+int Engine::load_blob_device(const void* d_src, size_t bytes) {
+    if (bytes < kHeaderBytes) return set_err(VT_ERR_FORMAT, "weight blob: truncated");
+    std::vector<uint8_t> head(kHeaderBytes);
+    HIPCHK(hipMemcpy(head.data(), d_src, kHeaderBytes, hipMemcpyDeviceToHost));
+    if (memcmp(head.data(), kMagic, 8) != 0) return set_err(VT_ERR_FORMAT, "weight blob: bad magic");
+    int32_t n_tensors;
+    memcpy(&n_tensors, head.data() + 8 + 10 * 4, 4);
+    const size_t tbl = kHeaderBytes + (size_t)std::max(n_tensors, 0) * kEntryBytes;
+    if (n_tensors <= 0 || tbl > bytes) return set_err(VT_ERR_FORMAT, "weight blob: bad table");
+    // host copy of header + table only; index_blob checks offsets against the full size
+    std::vector<uint8_t> hc(tbl);
+    HIPCHK(hipMemcpy(hc.data(), d_src, tbl, hipMemcpyDeviceToHost));
+    blob_bytes = bytes;
+    HIPCHK(hipMalloc((void**)&d_blob, blob_bytes));
+    HIPCHK(hipMemcpy(d_blob, d_src, blob_bytes, hipMemcpyDeviceToDevice));
+    hc.resize(tbl);
+    // index_blob only touches [0, tbl) of the host copy
+    return index_blob(hc.data(), blob_bytes);
+}
+
+template <typename T>
+static hipError_t dalloc0(T** p, size_t count) {
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, count * sizeof(T));
+}
+
+int Engine::alloc_buffers() {
+    const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
+    HIPCHK(dalloc0(&d_patches, M * d.kpad));
+    HIPCHK(dalloc0(&d_x, M * d.D));
+    HIPCHK(dalloc0(&d_ln, M * d.D));
+    HIPCHK(dalloc0(&d_qk, M * 2 * d.D));
+    HIPCHK(dalloc0(&d_vt, (size_t)B * d.H * 64 * d.npad));
+    HIPCHK(dalloc0(&d_attn, M * d.D));
+    HIPCHK(dalloc0(&d_mlp, M * d.mlp));
+    HIPCHK(dalloc0(&d_feat, Ms * d.D));
+    HIPCHK(dalloc0(&d_ta, Ms * d.C));
+    HIPCHK(dalloc0(&d_tb, Ms * d.C));
+    HIPCHK(dalloc0(&d_col, Ms * 9 * d.C));
+    HIPCHK(dalloc0(&d_headout, Ms * 8));
+    HIPCHK(dalloc0(&d_states, (size_t)B));
+    HIPCHK(dalloc0(&d_frames, (size_t)B));
+    HIPCHK(dalloc0(&d_results, (size_t)B));
+    HIPCHK(hipHostMalloc((void**)&h_frames, sizeof(FrameDesc) * B * RING));
+    HIPCHK(hipHostMalloc((void**)&h_results, sizeof(vt_result) * B));
+    HIPCHK(hipHostMalloc((void**)&h_state, sizeof(StreamState)));
+    memset(h_results, 0, sizeof(vt_result) * B);
+    for (int i = 0; i < RING; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
+    h_initialized.assign(B, 0);
+    return VT_OK;
+}
+
+double Engine::flops_encoder() const {
+    const double n = d.ntok, D = d.D;
+    const double per_layer = 2 * n * D * 3 * D + 2 * n * D * D + 4 * n * D * d.mlp + 4 * n * n * D;
+    return d.L * per_layer + 2 * n * (3.0 * d.patch * d.patch) * D;
+}
+double Engine::flops_head() const {
+    const double C = d.C;
+    return 2.0 * d.ns * (d.D * C + 27 * C * C + 8 * C);
+}
+
+// One hot-path pass over all B streams. With prof != nullptr every launch is bracketed by HIP
+// events on this engine's stream.
+int Engine::run_pass(Profiler* prof) {
+    const int M = B * d.ntok, Ms = B * d.ns, D = d.D;
+    hipError_t lerr = hipSuccess;
+    auto L = [&](const char* name, double flops, double bytes, auto&& fn) {
+        if (lerr != hipSuccess) return;
+        if (prof) {
+            Profiler::Rec r;
+            r.fam = prof->family(name);
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+            (void)hipEventRecord(r.a, stream);
+            lerr = fn();
+            (void)hipEventRecord(r.b, stream);
+            prof->recs.push_back(r);
+            prof->fams[r.fam].launches += 1;
+            prof->fams[r.fam].flops += flops;
+            prof->fams[r.fam].bytes += bytes;
+        } else {
+            lerr = fn();
+        }
+    };
+    auto gemm = [&](int epi, GemmArgs a) {
+        const double fl = 2.0 * a.M * a.N * a.K;
+        const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
+                          (epi == EPI_RESID || epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
+        L(gemm_name(epi, a.M, a.N), fl, by, [&] { return launch_gemm(a, epi, stream); });
+    };
+    auto tap = [&](int slot) {
+        if (taps && lerr == hipSuccess)
+            lerr = hipMemcpyAsync(d_taps + (size_t)slot * M * D, d_x, sizeof(float) * M * D,
+                                  hipMemcpyDeviceToDevice, stream);
+    };
+
+    // K1: crop + resize + normalise the search window of every stream -> patch rows
+    L("preproc_search", 0, (double)B * (d.S * d.S * 3 * 2 + 1.5 * d.S * d.S),
+      [&] { return launch_preproc(d_frames, d_states, d_patches, d, 0, B, false, stream); });
+    // K2: patch embedding (+bias +pos) -> f32 residual stream
+    {
+        GemmArgs a{};
+        a.A = d_patches; a.lda = d.kpad;
+        a.W = (const bf16_t*)find("patch_w")->ptr; a.ldw = d.kpad;
+        a.bias = (const float*)find("patch_b")->ptr;
+        a.M = M; a.N = D; a.K = d.kpad;
+        a.Cf = d_x; a.ldc = D;
+        a.pos = (const float*)find("pos")->ptr; a.pos_rows = d.ntok;
+        gemm(EPI_F32_POS, a);
+    }
+    tap(0);
+    const double ln_bytes = (double)M * D * 6;
+    for (int l = 0; l < d.L; ++l) {
+        const LayerW& w = layers[l];
+        L("layernorm", 0, ln_bytes, [&] {
+            return launch_layernorm(d_x, w.ln1_g, w.ln1_b, d_ln, M, D, M, 0, 0, d.ln_eps, stream);
+        });
+        {
+            GemmArgs a{};
+            a.A = d_ln; a.lda = D; a.W = w.qkv_w; a.ldw = D; a.bias = w.qkv_b;
+            a.M = M; a.N = 3 * D; a.K = D;
+            a.qk = d_qk; a.vt = d_vt; a.tokens = d.ntok; a.npad = d.npad; a.D = D;
+            gemm(EPI_QKV, a);
+        }
+        L("attention", 4.0 * B * (double)d.ntok * d.ntok * D, (double)M * D * 8, [&] {
+            return launch_attention(d_qk, d_vt, d_attn, B, d.ntok, d.H, d.npad, stream);
+        });
+        {
+            GemmArgs a{};
+            a.A = d_attn; a.lda = D; a.W = w.proj_w; a.ldw = D; a.bias = w.proj_b;
+            a.M = M; a.N = D; a.K = D; a.Cf = d_x; a.ldc = D;
+            gemm(EPI_RESID, a);
+        }
+        L("layernorm", 0, ln_bytes, [&] {
+            return launch_layernorm(d_x, w.ln2_g, w.ln2_b, d_ln, M, D, M, 0, 0, d.ln_eps, stream);
+        });
+        {
+            GemmArgs a{};
+            a.A = d_ln; a.lda = D; a.W = w.fc1_w; a.ldw = D; a.bias = w.fc1_b;
+            a.M = M; a.N = d.mlp; a.K = D; a.Cb = d_mlp; a.ldcb = d.mlp;
+            gemm(EPI_GELU_BF16, a);
+        }
+        {
+            GemmArgs a{};
+            a.A = d_mlp; a.lda = d.mlp; a.W = w.fc2_w; a.ldw = d.mlp; a.bias = w.fc2_b;
+            a.M = M; a.N = D; a.K = d.mlp; a.Cf = d_x; a.ldc = D;
+            gemm(EPI_RESID, a);
+        }
+        tap(1 + l);
+    }
+    // final LayerNorm on the search tokens only, compacted to [B*ns][D]
+    L("layernorm", 0, (double)Ms * D * 6, [&] {
+        return launch_layernorm(d_x, (const float*)find("norm_g")->ptr,
+                                (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
+                                d.nt, d.ln_eps, stream);
+    });
+    // centre head: 1x1 conv, three 3x3 convs (im2col + GEMM), then the f32 5-logit layer + decode
+    {
+        GemmArgs a{};
+        a.A = d_feat; a.lda = D; a.W = (const bf16_t*)find("head.w0")->ptr; a.ldw = D;
+        a.bias = (const float*)find("head.b0")->ptr;
+        a.M = Ms; a.N = d.C; a.K = D; a.Cb = d_ta; a.ldcb = d.C;
+        gemm(EPI_RELU_BF16, a);
+    }
+    bf16_t* cur = d_ta;
+    bf16_t* nxt = d_tb;
+    for (int k = 1; k <= 3; ++k) {
+        L("im2col3x3", 0, (double)Ms * d.C * 2 * 10,
+          [&] { return launch_im2col3x3(cur, d_col, B, d.gs, d.C, stream); });
+        GemmArgs a{};
+        const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
+        a.A = d_col; a.lda = 9 * d.C; a.W = (const bf16_t*)find(wn)->ptr; a.ldw = 9 * d.C;
+        a.bias = (const float*)find(bn)->ptr;
+        a.M = Ms; a.N = d.C; a.K = 9 * d.C; a.Cb = nxt; a.ldcb = d.C;
+        gemm(EPI_RELU_BF16, a);
+        std::swap(cur, nxt);
+    }
+    {
+        DecodeArgs a{};
+        a.t3 = cur;
+        a.w4 = (const float*)find("head.w4")->ptr;
+        a.b4 = (const float*)find("head.b4")->ptr;
+        a.hann = (const float*)find("hann")->ptr;
+        a.head_out = d_headout; a.states = d_states; a.results = d_results;
+        a.B = B; a.ns = d.ns; a.grid = d.gs; a.C = d.C;
+        a.success_threshold = success_threshold;
+        L("decode", 2.0 * Ms * d.C * 5, (double)Ms * d.C * 2, [&] { return launch_decode(a, stream); });
+    }
+    if (lerr != hipSuccess)
+        return set_err(VT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
+    HIPCHK(hipMemcpyAsync(h_results, d_results, sizeof(vt_result) * B, hipMemcpyDeviceToHost, stream));
+    return VT_OK;
+}
+
+int Engine::capture_graph() {
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_pass(nullptr);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(stream, &g);
+    if (rc != VT_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return set_err(VT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    graph = g;
+    HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    return VT_OK;
+}
+
+static int check_frame(const vt_frame& f) {
+    if (!f.plane0 || f.width < 16 || f.height < 16 || f.width > 16384 || f.height > 16384)
+        return set_err(VT_ERR_INVALID_ARG, "frame: null plane or size out of range");
+    if (f.format == VT_PIX_RGB8) {
+        if (f.stride0 < f.width * 3) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
+    } else if (f.format == VT_PIX_NV12) {
+        if (!f.plane1 || f.stride0 < f.width || f.stride1 < ((f.width + 1) & ~1))
+            return set_err(VT_ERR_INVALID_ARG, "nv12: null UV plane or stride too small");
+    } else {
+        return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", f.format);
+    }
+    return VT_OK;
+}
+
+static void to_desc(const vt_frame& f, FrameDesc* o) {
+    o->p0 = (const uint8_t*)f.plane0;
+    o->p1 = (const uint8_t*)f.plane1;
+    o->w = f.width; o->h = f.height; o->s0 = f.stride0; o->s1 = f.stride1; o->fmt = f.format;
+    o->pad = 0;
+}
+
+int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
+    if (b < 0 || b >= B || !f) return set_err(VT_ERR_INVALID_ARG, "init: bad stream index");
+    if (int rc = check_frame(*f)) return rc;
+    if (box.width < 1 || box.height < 1 || box.width > 32768 || box.height > 32768 ||
+        box.x < -32768 || box.y < -32768 || box.x > 32768 || box.y > 32768)
+        return set_err(VT_ERR_INVALID_ARG, "init: bbox %d,%d %dx%d out of range", box.x, box.y,
+                       box.width, box.height);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    memset(h_state, 0, sizeof(StreamState));
+    h_state->box[0] = (float)box.x; h_state->box[1] = (float)box.y;
+    h_state->box[2] = (float)box.width; h_state->box[3] = (float)box.height;
+    h_state->frame_w = f->width; h_state->frame_h = f->height;
+    h_state->initialized = 1;
+    HIPCHK(hipMemcpyAsync(d_states + b, h_state, sizeof(StreamState), hipMemcpyHostToDevice, stream));
+    FrameDesc* slot = h_frames;  // stream is idle: ring slot 0 is free
+    to_desc(*f, slot);
+    HIPCHK(hipMemcpyAsync(d_frames + b, slot, sizeof(FrameDesc), hipMemcpyHostToDevice, stream));
+    HIPCHK(launch_preproc(d_frames, d_states, d_patches, d, b, 1, true, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    h_initialized[b] = 1;
+    return VT_OK;
+}
+
+int Engine::enqueue(const vt_frame* frames, int n) {
+    if (!frames || n != B) return set_err(VT_ERR_INVALID_ARG, "enqueue: need exactly %d frames", B);
+    for (int b = 0; b < B; ++b) {
+        if (!h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d: update before init", b);
+        if (int rc = check_frame(frames[b])) return rc;
+    }
+    HIPCHK(hipSetDevice(device));
+    const int slot = ring_pos;
+    ring_pos = (ring_pos + 1) % RING;
+    HIPCHK(hipEventSynchronize(ring_ev[slot]));  // the copy that last used this slot is done
+    FrameDesc* hf = h_frames + (size_t)slot * B;
+    for (int b = 0; b < B; ++b) to_desc(frames[b], hf + b);
+    HIPCHK(hipMemcpyAsync(d_frames, hf, sizeof(FrameDesc) * B, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(ring_ev[slot], stream));
+    if (use_graph && !taps) {
+        if (!graph_exec)
+            if (int rc = capture_graph()) return rc;
+        HIPCHK(hipGraphLaunch(graph_exec, stream));
+        return VT_OK;
+    }
+    return run_pass(nullptr);
+}
+
+int Engine::wait(vt_result* out, int n) {
+    if (n > B) n = B;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (out)
+        for (int b = 0; b < n; ++b) out[b] = h_results[b];
+    return VT_OK;
+}
+
+// ---- construction ----------------------------------------------------------------------------------
+
+static int read_file(const char* path, std::vector<uint8_t>* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_err(VT_ERR_IO, "cannot open weights file '%s'", path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz <= 0) { fclose(f); return set_err(VT_ERR_IO, "weights file '%s' is empty", path); }
+    out->resize((size_t)sz);
+    size_t got = fread(out->data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) return set_err(VT_ERR_IO, "short read on '%s'", path);
+    return VT_OK;
+}
+
+static int check_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(VT_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU path",
+                       e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return set_err(VT_ERR_NO_DEVICE, "device %d out of range (have %d)", device_id, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+        return set_err(VT_ERR_NO_DEVICE, "cannot query device %d", device_id);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(VT_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only",
+                       device_id, prop.gcnArchName);
+    return VT_OK;
+}
+
+static int make_engine(const char* path, const void* d_src, size_t bytes, int device_id,
+                       const vt_config* cfg, int B, Engine** out) {
+    if (!out) return set_err(VT_ERR_INVALID_ARG, "null output handle");
+    *out = nullptr;
+    if (B < 1 || B > 4096) return set_err(VT_ERR_INVALID_ARG, "n_streams %d out of range", B);
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(gemm_prepare());
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return set_err(VT_ERR_OOM, "out of host memory");
+    e->device = device_id;
+    e->B = B;
+    int rc = VT_OK;
+    do {
+        hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (he != hipSuccess) { rc = set_err(VT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); break; }
+        if (path) {
+            std::vector<uint8_t> blob;
+            if ((rc = read_file(path, &blob))) break;
+            if ((rc = e->load_blob_host(blob))) break;
+        } else {
+            if ((rc = e->load_blob_device(d_src, bytes))) break;
+        }
+        e->success_threshold = e->d.success_threshold;
+        if (cfg && cfg->struct_size >= sizeof(vt_config)) {
+            if (cfg->success_threshold >= 0.0f) e->success_threshold = cfg->success_threshold;
+            e->use_graph = cfg->use_graph != 0;
+            if (cfg->max_frame_width > 0) e->max_w = cfg->max_frame_width;
+            if (cfg->max_frame_height > 0) e->max_h = cfg->max_frame_height;
+        }
+        if ((rc = e->alloc_buffers())) break;
+    } while (0);
+    if (rc != VT_OK) {
+        char keep[512];
+        memcpy(keep, g_err, sizeof(keep));
+        delete e;
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = e;
+    return VT_OK;
+}
+
+static void fill_info(const Engine* e, vt_model_info* o) {
+    memset(o, 0, sizeof(*o));
+    const ModelDims& d = e->d;
+    o->patch = d.patch; o->template_size = d.T; o->search_size = d.S; o->dim = d.D;
+    o->heads = d.H; o->layers = d.L; o->mlp_dim = d.mlp; o->head_channels = d.C;
+    o->tokens_template = d.nt; o->tokens_search = d.ns; o->kpad = d.kpad; o->score_grid = d.gs;
+    o->encoder_flops_per_frame = e->flops_encoder();
+    o->flops_per_frame = e->flops_encoder() + e->flops_head();
+    o->weight_bytes = e->blob_bytes;
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+
+struct vt_group { Engine* e; };
+struct vt_tracker { Engine* e; };
+
+extern "C" {
+
+void vt_config_default(vt_config* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(vt_config);
+    cfg->success_threshold = -1.0f;
+    cfg->use_graph = 1;
+    cfg->n_streams = 1;
+}
+const char* vt_last_error(void) { return g_err; }
+int vt_abi_version(void) { return VT_ABI_VERSION; }
+int vt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out) {
+    if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = nullptr;
+    const int B = (cfg && cfg->struct_size >= sizeof(vt_config) && cfg->n_streams > 0) ? cfg->n_streams : 1;
+    if (int rc = make_engine(weights_path, nullptr, 0, device_id, cfg, B, &e)) return rc;
+    *out = new vt_group{e};
+    return VT_OK;
+}
+int vt_group_create_from_device_blob(const void* d_blob, size_t bytes, int device_id,
+                                     const vt_config* cfg, vt_group** out) {
+    if (!d_blob || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = nullptr;
+    const int B = (cfg && cfg->struct_size >= sizeof(vt_config) && cfg->n_streams > 0) ? cfg->n_streams : 1;
+    if (int rc = make_engine(nullptr, d_blob, bytes, device_id, cfg, B, &e)) return rc;
+    *out = new vt_group{e};
+    return VT_OK;
+}
+void vt_group_destroy(vt_group* g) {
+    if (!g) return;
+    delete g->e;
+    delete g;
+}
+int vt_group_streams(const vt_group* g) { return g ? g->e->B : 0; }
+int vt_group_get_model_info(const vt_group* g, vt_model_info* out) {
+    if (!g || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    fill_info(g->e, out);
+    return VT_OK;
+}
+int vt_group_init_device(vt_group* g, int stream, const vt_frame* frame, vt_bbox box) {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    return g->e->init_stream(stream, frame, box);
+}
+int vt_group_enqueue_device(vt_group* g, const vt_frame* frames, int n) {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    return g->e->enqueue(frames, n);
+}
+int vt_group_wait(vt_group* g, vt_result* out, int n) {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    return g->e->wait(out, n);
+}
+int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out) {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    if (int rc = g->e->enqueue(frames, n)) return rc;
+    return g->e->wait(out, n);
+}
+void* vt_group_hip_stream(vt_group* g) { return g ? (void*)g->e->stream : nullptr; }
+
+int vt_group_enable_taps(vt_group* g, int enable) {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    Engine* e = g->e;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (enable && !e->d_taps)
+        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * e->B * e->d.ntok * e->d.D));
+    e->taps = enable != 0;
+    return VT_OK;
+}
+
+int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iters,
+                            vt_kernel_time* out, int max_out) {
+    if (!g || !frames || !out || iters < 1) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    Engine* e = g->e;
+    if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "profile: need exactly %d frames", e->B);
+    for (int b = 0; b < e->B; ++b)
+        if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    FrameDesc* hf = e->h_frames;
+    for (int b = 0; b < e->B; ++b) {
+        if (int rc = check_frame(frames[b])) return rc;
+        to_desc(frames[b], hf + b);
+    }
+    HIPCHK(hipMemcpyAsync(e->d_frames, hf, sizeof(FrameDesc) * e->B, hipMemcpyHostToDevice, e->stream));
+    Profiler prof;
+    for (int it = 0; it < iters; ++it)
+        if (int rc = e->run_pass(&prof)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (auto& r : prof.recs) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        prof.fams[r.fam].ms += ms;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    int k = 0;
+    for (auto& f : prof.fams) {
+        if (k >= max_out) break;
+        vt_kernel_time& o = out[k++];
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", f.name.c_str());
+        o.launches = f.launches / iters;
+        o.ms_total = (float)(f.ms / iters);
+        o.flops = f.flops / iters;
+        o.bytes = f.bytes / iters;
+    }
+    return k;
+}
+
+static int64_t copy_out_f32(const float* dsrc, int64_t count, float* out, int64_t cap) {
+    if (!out) return count;
+    if (cap < count) return set_err(VT_ERR_INVALID_ARG, "read_tensor: capacity %lld < %lld", (long long)cap, (long long)count);
+    if (hipMemcpy(out, dsrc, sizeof(float) * count, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(VT_ERR_HIP, "read_tensor: copy failed");
+    return count;
+}
+static int64_t copy_out_bf16(const bf16_t* dsrc, int64_t count, float* out, int64_t cap) {
+    if (!out) return count;
+    if (cap < count) return set_err(VT_ERR_INVALID_ARG, "read_tensor: capacity %lld < %lld", (long long)cap, (long long)count);
+    std::vector<bf16_t> tmp((size_t)count);
+    if (hipMemcpy(tmp.data(), dsrc, 2 * count, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(VT_ERR_HIP, "read_tensor: copy failed");
+    for (int64_t i = 0; i < count; ++i) {
+        uint32_t u = ((uint32_t)tmp[i]) << 16;
+        memcpy(out + i, &u, 4);
+    }
+    return count;
+}
+
+int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* out, int64_t capacity) {
+    if (!g || !name) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+        return set_err(VT_ERR_HIP, "read_tensor: sync failed");
+    const ModelDims& d = e->d;
+    const std::string n(name);
+    const size_t b = (size_t)stream;
+    if (n == "patches") return copy_out_bf16(e->d_patches + b * d.ntok * d.kpad, (int64_t)d.ntok * d.kpad, out, capacity);
+    if (n == "feat") return copy_out_bf16(e->d_feat + b * d.ns * d.D, (int64_t)d.ns * d.D, out, capacity);
+    if (n == "attn") return copy_out_bf16(e->d_attn + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
+    if (n == "head_t3") return copy_out_bf16(e->d_tb + b * d.ns * d.C, (int64_t)d.ns * d.C, out, capacity);
+    if (n == "head_out") return copy_out_f32(e->d_headout + b * d.ns * 8, (int64_t)d.ns * 8, out, capacity);
+    if (n == "x") return copy_out_f32(e->d_x + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
+    if (n == "state") {
+        static_assert(sizeof(StreamState) % 4 == 0, "state size");
+        return copy_out_f32((const float*)(e->d_states + b), sizeof(StreamState) / 4, out, capacity);
+    }
+    int slot = -1;
+    if (n == "tokens0") slot = 0;
+    else if (n.rfind("layer", 0) == 0) slot = 1 + atoi(n.c_str() + 5);
+    if (slot >= 0 && slot <= d.L) {
+        if (!e->d_taps) return set_err(VT_ERR_INVALID_ARG, "taps not enabled (vt_group_enable_taps)");
+        const size_t M = (size_t)e->B * d.ntok;
+        return copy_out_f32(e->d_taps + ((size_t)slot * M + b * d.ntok) * d.D, (int64_t)d.ntok * d.D, out, capacity);
+    }
+    return set_err(VT_ERR_INVALID_ARG, "unknown tensor '%s'", name);
+}
+
+// ---- single-stream drop-in --------------------------------------------------------------------------
+
+int vt_create(const char* weights_path, int device_id, const vt_config* cfg, vt_tracker** out) {
+    if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = nullptr;
+    if (int rc = make_engine(weights_path, nullptr, 0, device_id, cfg, 1, &e)) return rc;
+    *out = new vt_tracker{e};
+    return VT_OK;
+}
+int vt_create_from_device_blob(const void* d_blob, size_t bytes, int device_id, const vt_config* cfg,
+                               vt_tracker** out) {
+    if (!d_blob || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = nullptr;
+    if (int rc = make_engine(nullptr, d_blob, bytes, device_id, cfg, 1, &e)) return rc;
+    *out = new vt_tracker{e};
+    return VT_OK;
+}
+void vt_destroy(vt_tracker* t) {
+    if (!t) return;
+    delete t->e;
+    delete t;
+}
+int vt_get_model_info(const vt_tracker* t, vt_model_info* out) {
+    if (!t || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    fill_info(t->e, out);
+    return VT_OK;
+}
+
+// copy a host frame into the engine's staging buffer (tight rows) and describe it
+static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
+                            int s0, int s1, vt_frame* f) {
+    if (!p0 || w < 16 || h < 16) return set_err(VT_ERR_INVALID_ARG, "null frame or size < 16");
+    if (w > e->max_w || h > e->max_h)
+        return set_err(VT_ERR_INVALID_ARG, "frame %dx%d exceeds configured max %dx%d", w, h, e->max_w, e->max_h);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t need = (size_t)e->max_w * e->max_h * 3 + 256;
+    if (!e->d_stage) {
+        HIPCHK(hipMalloc((void**)&e->d_stage, need));
+        e->stage_bytes = need;
+    }
+    // the previous pass has finished reading the staging buffer: every sync call waits
+    memset(f, 0, sizeof(*f));
+    f->width = w; f->height = h; f->format = fmt;
+    if (fmt == VT_PIX_RGB8) {
+        if (s0 < 3 * w) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
+        HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)w * 3, p0, (size_t)s0, (size_t)w * 3, h,
+                                hipMemcpyHostToDevice, e->stream));
+        f->plane0 = e->d_stage; f->stride0 = w * 3;
+    } else {
+        if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
+        const int uvw = (w + 1) & ~1, uvh = (h + 1) / 2;
+        uint8_t* duv = e->d_stage + (((size_t)w * h + 255) & ~(size_t)255);
+        HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)w, p0, (size_t)s0, (size_t)w, h, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpy2DAsync(duv, (size_t)uvw, p1, (size_t)s1, (size_t)uvw, uvh, hipMemcpyHostToDevice, e->stream));
+        f->plane0 = e->d_stage; f->plane1 = duv; f->stride0 = w; f->stride1 = uvw;
+    }
+    // the caller may overwrite its buffer as soon as we return (src/pipeline.rs:125)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return VT_OK;
+}
+
+static int do_init(vt_tracker* t, const vt_frame* f, vt_bbox box) { return t->e->init_stream(0, f, box); }
+static int do_update(vt_tracker* t, const vt_frame* f, vt_result* out) {
+    if (!out) return set_err(VT_ERR_INVALID_ARG, "null result pointer");
+    memset(out, 0, sizeof(*out));
+    if (int rc = t->e->enqueue(f, 1)) return rc;
+    return t->e->wait(out, 1);
+}
+
+int vt_init_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_bbox box) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f;
+    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, &f)) return rc;
+    return do_init(t, &f, box);
+}
+int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_result* out) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
+    vt_frame f;
+    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, &f)) return rc;
+    return do_update(t, &f, out);
+}
+int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
+                 int uv_stride, vt_bbox box) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f;
+    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, &f)) return rc;
+    return do_init(t, &f, box);
+}
+int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
+                   int uv_stride, vt_result* out) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
+    vt_frame f;
+    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, &f)) return rc;
+    return do_update(t, &f, out);
+}
+
+static vt_frame dev_frame(int fmt, const void* p0, const void* p1, int w, int h, int s0, int s1) {
+    vt_frame f;
+    memset(&f, 0, sizeof(f));
+    f.plane0 = p0; f.plane1 = p1; f.width = w; f.height = h; f.stride0 = s0; f.stride1 = s1;
+    f.format = fmt;
+    return f;
+}
+int vt_init_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_bbox box) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f = dev_frame(VT_PIX_RGB8, d_rgb, nullptr, w, h, stride_bytes, 0);
+    return do_init(t, &f, box);
+}
+int vt_update_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_result* out) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f = dev_frame(VT_PIX_RGB8, d_rgb, nullptr, w, h, stride_bytes, 0);
+    return do_update(t, &f, out);
+}
+int vt_init_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h, int y_stride,
+                        int uv_stride, vt_bbox box) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f = dev_frame(VT_PIX_NV12, d_y, d_uv, w, h, y_stride, uv_stride);
+    return do_init(t, &f, box);
+}
+int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h, int y_stride,
+                          int uv_stride, vt_result* out) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f = dev_frame(VT_PIX_NV12, d_y, d_uv, w, h, y_stride, uv_stride);
+    return do_update(t, &f, out);
+}
+
+// a single tracker viewed as a group of one (taps, profiling, stream handle)
+vt_group* vt_tracker_as_group(vt_tracker* t) {
+    static thread_local vt_group view;
+    if (!t) return nullptr;
+    view.e = t->e;
+    return &view;
+}
+
+// ---- reference colour converter ------------------------------------------------------------------------
+
+static size_t nv12_bytes_read(size_t w, size_t h) {
+    if (!w || !h) return 0;
+    const size_t uv_rows = (h + 1) / 2;
+    const size_t last = (uv_rows - 1) * w + ((w & 1) ? w : w - 1);
+    return w * h + last + 1;
+}
+
+int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w, int h, void* d_rgb_out,
+                           void* hip_stream) {
+    if (!d_nv12 || !d_rgb_out || w <= 0 || h <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (len < (size_t)w * h * 3 / 2) {  // src/nv12_convert.rs:48-50: short buffer -> zero frame
+        HIPCHK(hipMemsetAsync(d_rgb_out, 0, (size_t)w * h * 3, st));
+        return VT_OK;
+    }
+    if (len < nv12_bytes_read(w, h))
+        return set_err(VT_ERR_SHORT_BUFFER, "nv12 buffer of %zu bytes is shorter than the %zu the "
+                       "conversion of a %dx%d frame reads", len, nv12_bytes_read(w, h), w, h);
+    HIPCHK(launch_nv12_to_rgb8((const uint8_t*)d_nv12, w, h, (uint8_t*)d_rgb_out, st));
+    return VT_OK;
+}
+
+int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h, uint8_t* rgb_out) {
+    if (!nv12 || !rgb_out || w <= 0 || h <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    const size_t out_bytes = (size_t)w * h * 3;
+    if (len < (size_t)w * h * 3 / 2) {
+        memset(rgb_out, 0, out_bytes);
+        return VT_OK;
+    }
+    if (len < nv12_bytes_read(w, h))
+        return set_err(VT_ERR_SHORT_BUFFER, "nv12 buffer too short for a %dx%d frame", w, h);
+    uint8_t *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void**)&din, len));
+    hipError_t e = hipMalloc((void**)&dout, out_bytes);
+    if (e != hipSuccess) { (void)hipFree(din); return set_err(VT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = VT_OK;
+    if ((e = hipMemcpy(din, nv12, len, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = launch_nv12_to_rgb8(din, w, h, dout, nullptr)) != hipSuccess ||
+        (e = hipMemcpy(rgb_out, dout, out_bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = set_err(VT_ERR_HIP, "nv12_to_rgb8: %s", hipGetErrorString(e));
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
+
+// ---- operator-level entry points ---------------------------------------------------------------------------
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+};
+
+int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* c_inout,
+                    int M, int N, int K, int epilogue) {
+    if (!a || !w || !c_inout || M <= 0 || N <= 0 || K <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (N % 64 || K % 64) return set_err(VT_ERR_INVALID_ARG, "gemm: N and K must be multiples of 64");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(gemm_prepare());
+    DevBuf da, dw, db, dc, dcb;
+    HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
+    HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
+    HIPCHK(hipMemcpy(da.p, a, (size_t)M * K * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    std::vector<float> zb((size_t)N, 0.0f);
+    HIPCHK(hipMemcpy(db.p, bias ? bias : zb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.p, c_inout, (size_t)M * N * 4, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
+    g.M = M; g.N = N; g.K = K; g.Cf = (float*)dc.p; g.ldc = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    int epi;
+    switch (epilogue) {
+        case 0: epi = EPI_F32; break;
+        case 1: epi = EPI_RESID; break;
+        case 2: epi = EPI_GELU_BF16; break;
+        case 3: epi = EPI_RELU_BF16; break;
+        default: return set_err(VT_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+    }
+    HIPCHK(launch_gemm(g, epi, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    if (epi == EPI_F32 || epi == EPI_RESID) {
+        HIPCHK(hipMemcpy(c_inout, dc.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<bf16_t> tmp((size_t)M * N);
+        HIPCHK(hipMemcpy(tmp.data(), dcb.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            uint32_t u = ((uint32_t)tmp[i]) << 16;
+            memcpy(c_inout + i, &u, 4);
+        }
+    }
+    return VT_OK;
+}
+
+int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* qk_out,
+                   float* vt_out, int B, int tokens, int D) {
+    // QKV GEMM with the attention-layout epilogue: qk_out [B*tokens][2D], vt_out [B*H][64][npad]
+    if (!a || !w || !bias || !qk_out || !vt_out || B <= 0 || tokens <= 0 || D % 64 || (tokens & 3))
+        return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(gemm_prepare());
+    const int M = B * tokens, H = D / 64, npad = (tokens + 31) / 32 * 32;
+    DevBuf da, dw, db, dqk, dvt;
+    HIPCHK(da.alloc((size_t)M * D * 2)); HIPCHK(dw.alloc((size_t)3 * D * D * 2)); HIPCHK(db.alloc((size_t)3 * D * 4));
+    HIPCHK(dqk.alloc((size_t)M * 2 * D * 2)); HIPCHK(dvt.alloc((size_t)B * H * 64 * npad * 2));
+    HIPCHK(hipMemcpy(da.p, a, (size_t)M * D * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw.p, w, (size_t)3 * D * D * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, bias, (size_t)3 * D * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dvt.p, 0, (size_t)B * H * 64 * npad * 2));
+    GemmArgs g{};
+    g.A = (const bf16_t*)da.p; g.lda = D; g.W = (const bf16_t*)dw.p; g.ldw = D; g.bias = (const float*)db.p;
+    g.M = M; g.N = 3 * D; g.K = D; g.qk = (bf16_t*)dqk.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
+    HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    auto widen = [](const DevBuf& d, size_t count, float* out) -> hipError_t {
+        std::vector<bf16_t> tmp(count);
+        hipError_t e = hipMemcpy(tmp.data(), d.p, count * 2, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        for (size_t i = 0; i < count; ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
+        return hipSuccess;
+    };
+    HIPCHK(widen(dqk, (size_t)M * 2 * D, qk_out));
+    HIPCHK(widen(dvt, (size_t)B * H * 64 * npad, vt_out));
+    return VT_OK;
+}
+
+int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v, float* out,
+                         int B, int N, int H) {
+    if (!q || !k || !v || !out || B <= 0 || N <= 0 || H <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    const int D = H * 64, M = B * N, npad = (N + 31) / 32 * 32;
+    // host-side packing into the layouts the QKV epilogue produces
+    std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad, 0);
+    for (int m = 0; m < M; ++m) {
+        memcpy(&qk[(size_t)m * 2 * D], q + (size_t)m * D, (size_t)D * 2);
+        memcpy(&qk[(size_t)m * 2 * D + D], k + (size_t)m * D, (size_t)D * 2);
+        const int b = m / N, t = m % N;
+        for (int c = 0; c < D; ++c)
+            vt[((size_t)(b * H + c / 64) * 64 + c % 64) * npad + t] = v[(size_t)m * D + c];
+    }
+    DevBuf dqk, dvt, dout;
+    HIPCHK(dqk.alloc(qk.size() * 2)); HIPCHK(dvt.alloc(vt.size() * 2)); HIPCHK(dout.alloc((size_t)M * D * 2));
+    HIPCHK(hipMemcpy(dqk.p, qk.data(), qk.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dvt.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(launch_attention((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<bf16_t> tmp((size_t)M * D);
+    HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
+    return VT_OK;
+}
+
+int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta, float* y, int M, int D) {
+    if (!x || !gamma || !beta || !y || M <= 0 || D % 128) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    DevBuf dx, dg, db, dy;
+    HIPCHK(dx.alloc((size_t)M * D * 4)); HIPCHK(dg.alloc((size_t)D * 4)); HIPCHK(db.alloc((size_t)D * 4)); HIPCHK(dy.alloc((size_t)M * D * 2));
+    HIPCHK(hipMemcpy(dx.p, x, (size_t)M * D * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dg.p, gamma, (size_t)D * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, beta, (size_t)D * 4, hipMemcpyHostToDevice));
+    HIPCHK(launch_layernorm((const float*)dx.p, (const float*)dg.p, (const float*)db.p, (bf16_t*)dy.p, M, D, M, 0, 0, 1e-6f, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<bf16_t> tmp((size_t)M * D);
+    HIPCHK(hipMemcpy(tmp.data(), dy.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(y + i, &u, 4); }
+    return VT_OK;
+}
+
+}  // extern "C"

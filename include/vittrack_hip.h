@@ -1,0 +1,231 @@
+/*
+ * vittrack_hip.h — C ABI of libvittrack_hip.so, the MI355X (gfx950) tracker hot path.
+ *
+ * This is the drop-in boundary for the reference's `vit_tracker` crate API
+ * (`VitTrack::{new, init, update}`, `BBox`), which the reference host calls at
+ *   - src/tracker_context.rs:21   VitTrack::new(model_path)        -> vt_create
+ *   - src/tracker_context.rs:88   tracker.init(full_image, bbox)   -> vt_init_rgb8 / vt_init_nv12
+ *   - src/tracker_context.rs:90   tracker.update(full_image)       -> vt_update_rgb8 / vt_update_nv12
+ *   - src/tracker_context.rs:120  tracker.update(full_image)       -> vt_update_rgb8 / vt_update_nv12
+ *   - src/selection_state.rs:44   BBox::new(x, y, w, h)            -> vt_bbox
+ *   - src/tracker_context.rs:94   BBox::from_array(&result.bbox)   -> vt_result.bbox
+ * and for the reference's own colour converter
+ *   - src/nv12_convert.rs:46      nv12_full_to_rgb_parallel        -> vt_nv12_to_rgb8
+ *
+ * Rules that follow from the reference call sites:
+ *   - plain pointers and sizes only; no C++/torch types cross this line;
+ *   - every call is synchronous with respect to the caller's frame buffer: on
+ *     return the library no longer reads it (the host draws overlays into the
+ *     same buffer right after, src/pipeline.rs:125);
+ *   - a handle has no thread affinity (created on the main thread, used on the
+ *     GStreamer streaming thread, src/pipeline.rs:55-67); calls on ONE handle
+ *     must be serialised by the caller (the reference holds a Mutex);
+ *   - nothing throws or aborts across the boundary (release profile is
+ *     panic="abort", Cargo.toml:37): every entry returns a vt_status code and
+ *     vt_last_error() gives the text;
+ *   - the accept gate `success && score > 0.25` stays on the caller side
+ *     (src/tracker_context.rs:93,122).
+ *
+ * There is no CPU fallback behind this ABI: if no gfx950 device is present
+ * vt_create fails with VT_ERR_NO_DEVICE.
+ */
+#ifndef VITTRACK_HIP_H
+#define VITTRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_ABI_VERSION 1
+
+typedef enum vt_status {
+    VT_OK = 0,
+    VT_ERR_INVALID_ARG = -1,
+    VT_ERR_NO_DEVICE = -2,
+    VT_ERR_IO = -3,          /* weights file missing / unreadable */
+    VT_ERR_FORMAT = -4,      /* weights blob malformed or unsupported shape */
+    VT_ERR_HIP = -5,         /* HIP runtime error (text in vt_last_error) */
+    VT_ERR_NOT_INITIALIZED = -6, /* update before init */
+    VT_ERR_SHORT_BUFFER = -7,
+    VT_ERR_OOM = -8
+} vt_status;
+
+/* ≙ vit_tracker::BBox { x, y, width, height: i32 } (src/selection_state.rs:44,
+ * src/tracker_context.rs:85) */
+typedef struct vt_bbox {
+    int32_t x, y, width, height;
+} vt_bbox;
+
+/* ≙ the value returned by VitTrack::update: fields success / score / bbox as
+ * used at src/tracker_context.rs:92-95,122-125 */
+typedef struct vt_result {
+    int32_t success;
+    float score;
+    vt_bbox bbox;
+} vt_result;
+
+typedef struct vt_config {
+    uint32_t struct_size;      /* = sizeof(vt_config); lets the struct grow */
+    float success_threshold;   /* result.success = score >= this; <0 → blob default (0.20) */
+    int32_t use_graph;         /* 1 (default): replay the frame as a hipGraph; 0: eager launches */
+    int32_t n_streams;         /* vt_group_create only: independent tracked streams on this GPU */
+    int32_t max_frame_width;   /* staging size for host-pointer calls; 0 → 3840 */
+    int32_t max_frame_height;  /* 0 → 2160 */
+    int32_t reserved[8];
+} vt_config;
+
+typedef struct vt_model_info {
+    int32_t patch, template_size, search_size, dim, heads, layers, mlp_dim;
+    int32_t head_channels, tokens_template, tokens_search, kpad;
+    int32_t score_grid;        /* search_size / patch */
+    double flops_per_frame;    /* algorithmic FLOPs of one update (encoder+patch+head) */
+    double encoder_flops_per_frame; /* encoder + patch-embed only */
+    uint64_t weight_bytes;
+} vt_model_info;
+
+typedef struct vt_tracker vt_tracker; /* one tracked stream  ≙ VitTrack */
+typedef struct vt_group vt_group;     /* B independent streams batched on one GPU */
+
+void vt_config_default(vt_config* cfg);
+const char* vt_last_error(void);       /* thread-local text of the last failure */
+int vt_abi_version(void);
+int vt_device_count(void);             /* gfx950 devices visible; 0 → vt_create fails */
+
+/* ---- single stream: the literal drop-in ------------------------------------------------ */
+
+/* ≙ VitTrack::new(model_path) (src/tracker_context.rs:21). */
+int vt_create(const char* weights_path, int device_id, const vt_config* cfg, vt_tracker** out);
+/* Same, with the weight blob already in this device's HBM (after the RCCL start-up broadcast,
+ * SURVEY.md §8e). The library makes its own copy; the caller may free d_blob on return. */
+int vt_create_from_device_blob(const void* d_blob, size_t bytes, int device_id,
+                               const vt_config* cfg, vt_tracker** out);
+void vt_destroy(vt_tracker* t);
+int vt_get_model_info(const vt_tracker* t, vt_model_info* out);
+
+/* ≙ tracker.init(&ArrayView3<u8>, bbox) with the (H,W,3) RGB8 view of src/pipeline_ir.rs:142 /
+ * src/nv12_convert.rs:90: C-contiguous rows of `stride_bytes` (>= 3*w), channel order R,G,B. */
+int vt_init_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_bbox box);
+/* ≙ tracker.update(&ArrayView3<u8>) -> Result<{success, score, bbox}> */
+int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes,
+                   vt_result* out);
+
+/* Fused ingest: the host skips nv12_full_to_rgb_parallel (src/pipeline.rs:105); every pixel the
+ * tracker samples goes through exactly the reference's integer conversion
+ * (src/nv12_convert.rs:109-147). y/uv are the two NV12 planes; strides in bytes. */
+int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
+                 int uv_stride, vt_bbox box);
+int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h,
+                   int y_stride, int uv_stride, vt_result* out);
+
+/* Same four calls with the frame already resident in this GPU's HBM (device pointers). */
+int vt_init_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes,
+                        vt_bbox box);
+int vt_update_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes,
+                          vt_result* out);
+int vt_init_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h,
+                        int y_stride, int uv_stride, vt_bbox box);
+int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h,
+                          int y_stride, int uv_stride, vt_result* out);
+
+/* ---- B streams on one GPU (one stream per camera; no cross-stream data flow) ------------ */
+
+typedef enum vt_pixfmt { VT_PIX_RGB8 = 0, VT_PIX_NV12 = 1 } vt_pixfmt;
+
+typedef struct vt_frame {        /* one device-resident frame */
+    const void* plane0;          /* RGB8: packed pixels; NV12: Y plane */
+    const void* plane1;          /* NV12: interleaved UV plane; RGB8: NULL */
+    int32_t width, height;
+    int32_t stride0, stride1;    /* bytes */
+    int32_t format;              /* vt_pixfmt */
+    int32_t reserved;
+} vt_frame;
+
+int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out);
+int vt_group_create_from_device_blob(const void* d_blob, size_t bytes, int device_id,
+                                     const vt_config* cfg, vt_group** out);
+void vt_group_destroy(vt_group* g);
+int vt_group_streams(const vt_group* g);
+int vt_group_get_model_info(const vt_group* g, vt_model_info* out);
+/* (re)initialise stream `stream` of the group on a device-resident frame */
+int vt_group_init_device(vt_group* g, int stream, const vt_frame* frame, vt_bbox box);
+/* One hot-path pass: frames[i] feeds stream i (n == vt_group_streams). Asynchronous: the pass is
+ * enqueued on the group's HIP stream; results land in the group's pinned result ring. */
+int vt_group_enqueue_device(vt_group* g, const vt_frame* frames, int n);
+/* Wait for every enqueued pass and copy the results of the LAST pass (n entries). */
+int vt_group_wait(vt_group* g, vt_result* out, int n);
+/* enqueue + wait */
+int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out);
+/* HIP stream the group launches on (hipStream_t as void*), for event timing by the caller */
+void* vt_group_hip_stream(vt_group* g);
+
+/* ---- reference colour converter on the GPU ---------------------------------------------- */
+
+/* ≙ nv12_full_to_rgb_parallel(nv12_data, width, height) (src/nv12_convert.rs:46-92): packed NV12
+ * buffer (Y plane then interleaved UV, stride == width) -> (H,W,3) RGB8. Bit-exact with the
+ * reference, including the all-zero frame when len < w*h*3/2 (src/nv12_convert.rs:48-50). For odd
+ * w or h the reference reads past w*h*3/2; here len must cover those reads or the call fails with
+ * VT_ERR_SHORT_BUFFER. Host pointers. */
+int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h, uint8_t* rgb_out);
+/* device-pointer form (d_rgb_out: w*h*3 bytes); enqueued on hip_stream (NULL → default) */
+int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w, int h,
+                           void* d_rgb_out, void* hip_stream);
+
+/* ---- per-kernel timing and stage taps (parity tests, bench roofline) -------------------- */
+
+typedef struct vt_kernel_time {
+    char name[48];       /* kernel family, e.g. "gemm_bf16_resid" */
+    int32_t launches;    /* launches of that family in one pass */
+    float ms_total;      /* summed HIP-event time of those launches in one pass */
+    double flops;        /* algorithmic FLOPs of those launches (0 for byte-bound kernels) */
+    double bytes;        /* algorithmic bytes of those launches */
+} vt_kernel_time;
+
+/* Run `iters` eager passes over `frames` with HIP events around every launch (events on the
+ * group's own stream) and return per-family averages per pass. Advances tracker state like
+ * `iters` updates. Returns the number of families written (<= max_out) or a negative vt_status. */
+int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iters,
+                            vt_kernel_time* out, int max_out);
+
+/* Stage taps: when enabled the pass runs eagerly and keeps a copy of the residual stream after the
+ * patch embedding and after every encoder block (for stage-level parity tests). */
+int vt_group_enable_taps(vt_group* g, int enable);
+/* A single tracker viewed as a group of one (taps, profiling, stream handle). The view is
+ * thread-local and valid until the next call of this function on the same thread. */
+vt_group* vt_tracker_as_group(vt_tracker* t);
+
+/* Copy an intermediate tensor of the last pass to the host as float32.
+ * names: "patches" [N,Kpad], "tokens0" [N,D], "layer<i>" [N,D] (residual stream after block i;
+ * both need taps), "x" [N,D] (final residual stream), "attn" [N,D] (last block's attention output),
+ * "feat" [Ns,D], "head_t3" [Ns,C], "head_out" [Ns,8] (score,ox,oy,w,h logits),
+ * "state" (the stream's device state record as raw 32-bit words).
+ * Returns the element count, or a negative vt_status. With out == NULL only the count. */
+int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* out,
+                             int64_t capacity);
+
+/* ---- operator-level entry points (numerics tests call the same kernels the pass uses) ---- */
+
+/* C[M,N] (f32) = A[M,K] (bf16 bits) x W[N,K]^T (bf16 bits) + bias[N]; epilogue:
+ * 0 = f32 store, 1 = C += (residual), 2 = GELU -> bf16 (returned widened to f32),
+ * 3 = ReLU -> bf16 (widened). Host pointers. K % 64 == 0, N % 64 == 0. */
+int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
+                    float* c_inout, int M, int N, int K, int epilogue);
+/* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
+ * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
+ * npad = tokens rounded up to 32, padding zero); bf16 results widened to f32. */
+int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
+                   float* qk_out, float* vt_out, int B, int tokens, int D);
+/* out[B,N,H*64] (bf16 widened to f32) = softmax(q k^T) v per head; q,k,v: [B,N,H*64] bf16 bits
+ * (q already scaled). */
+int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                         float* out, int B, int N, int H);
+/* y[M,D] (bf16 widened) = LayerNorm(x[M,D] f32; gamma, beta, eps=1e-6) */
+int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta,
+                    float* y, int M, int D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITTRACK_HIP_H */

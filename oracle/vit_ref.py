@@ -1,0 +1,287 @@
+"""NumPy restatement of the tracker below the VitTrack::{init, update} boundary.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+What it follows:
+  * NV12 -> RGB and crop/resize/normalise/decode: oracle/vt_oracle.c through ctypes (the NV12
+    part restates /root/reference/src/nv12_convert.rs:8-169).
+  * `init` / `update` call shape: /root/reference/src/tracker_context.rs:88,90,120 (init returns
+    nothing the caller uses; update returns {success, score, bbox}).
+  * The network itself (patch-embed, joint template+search encoder, centre head) has NO reference
+    definition — the reference runs an un-vendored RKNN model. It follows this
+    build's specification in DESIGN.md §2/§3. PARITY UNPINNED against the reference.
+
+Quantisation points mirror the HIP path: GEMM operands are bf16 (weights are stored bf16;
+activations are rounded to bf16 exactly where the HIP kernels round them), accumulation,
+LayerNorm, softmax and the residual stream are float32. What remains different between the two
+is float32 summation order (and expf/erff last-bit differences).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+from scipy.special import erf
+
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(_build.build())
+        c_u8p = ctypes.POINTER(ctypes.c_uint8)
+        c_fp = ctypes.POINTER(ctypes.c_float)
+        _lib.vto_nv12_to_rgb8.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_size_t, c_u8p, ctypes.c_int]
+        _lib.vto_nv12_to_rgb8.restype = ctypes.c_int
+        _lib.vto_nv12_bytes_read.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+        _lib.vto_nv12_bytes_read.restype = ctypes.c_size_t
+        _lib.vto_yuv_to_rgb_px.argtypes = [ctypes.c_uint8] * 3 + [c_u8p]
+        _lib.vto_crop_geometry.argtypes = [c_fp, ctypes.c_float, ctypes.c_int, c_fp]
+        _lib.vto_preproc.argtypes = [c_u8p, c_u8p] + [ctypes.c_int] * 5 + [
+            c_fp, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp,
+            ctypes.POINTER(ctypes.c_uint16)]
+        _lib.vto_decode.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
+                                    c_fp, ctypes.POINTER(ctypes.c_int32)]
+    return _lib
+
+
+def _u8p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+# ---- bf16 ---------------------------------------------------------------------------------
+
+def f32_to_bf16_bits(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))
+            >> np.uint32(16)).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b):
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(
+        np.float32)
+
+
+def bf16r(x):
+    """round float32 values to the nearest bf16, returned as float32"""
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# ---- colour conversion (reference stage) -----------------------------------------------------
+
+def nv12_to_rgb8(nv12: np.ndarray, w: int, h: int, nthreads: int = 1):
+    """≙ nv12_full_to_rgb_parallel (src/nv12_convert.rs:46). -> ((h,w,3) uint8, status)."""
+    nv12 = np.ascontiguousarray(nv12, np.uint8)
+    out = np.empty((h, w, 3), np.uint8)
+    st = lib().vto_nv12_to_rgb8(_u8p(nv12), nv12.size, w, h, _u8p(out), nthreads)
+    return out, st
+
+
+def yuv_px(y, u, v):
+    o = np.zeros(3, np.uint8)
+    lib().vto_yuv_to_rgb_px(int(y), int(u), int(v), _u8p(o))
+    return tuple(int(x) for x in o)
+
+
+# ---- frames ---------------------------------------------------------------------------------
+
+class Frame:
+    """RGB8 (H,W,3) view (≙ ArrayView3<u8>, src/pipeline_ir.rs:142) or NV12 planes."""
+
+    def __init__(self, fmt, p0, p1, w, h, s0, s1):
+        self.fmt, self.p0, self.p1, self.w, self.h, self.s0, self.s1 = fmt, p0, p1, w, h, s0, s1
+
+    @staticmethod
+    def rgb8(arr):
+        arr = np.ascontiguousarray(arr, np.uint8)
+        h, w, _ = arr.shape
+        return Frame(0, arr, None, w, h, w * 3, 0)
+
+    @staticmethod
+    def nv12(buf, w, h):
+        """packed NV12 buffer, stride == width (src/nv12_convert.rs:53-54)"""
+        buf = np.ascontiguousarray(buf, np.uint8).reshape(-1)
+        return Frame(1, buf[: w * h], buf[w * h:], w, h, w, w)
+
+
+def crop_geometry(box, factor, out_size):
+    b = np.asarray(box, np.float32)
+    geo = np.zeros(4, np.float32)
+    lib().vto_crop_geometry(_fp(b), ctypes.c_float(factor), out_size, _fp(geo))
+    return geo
+
+
+def preproc(frame: Frame, box, factor, out_size, patch, kpad, norm_a, norm_b):
+    """-> patch matrix [(out_size/patch)^2, kpad] of bf16 bits"""
+    g = out_size // patch
+    out = np.zeros((g * g, kpad), np.uint16)
+    b = np.asarray(box, np.float32)
+    na = np.ascontiguousarray(norm_a, np.float32)
+    nb = np.ascontiguousarray(norm_b, np.float32)
+    p1 = _u8p(frame.p1) if frame.p1 is not None else None
+    lib().vto_preproc(_u8p(frame.p0), p1, frame.w, frame.h, frame.s0, frame.s1, frame.fmt, _fp(b),
+                      ctypes.c_float(factor), out_size, patch, kpad, _fp(na), _fp(nb),
+                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+    return out
+
+
+# ---- the network ------------------------------------------------------------------------------
+
+def layernorm(x, g, b, eps):
+    x = x.astype(np.float32)
+    mean = x.mean(axis=-1, keepdims=True, dtype=np.float32)
+    xc = x - mean
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=np.float32)
+    rstd = (np.float32(1.0) / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    return (xc * rstd) * g.reshape(1, -1) + b.reshape(1, -1)
+
+
+def gelu(x):
+    x = x.astype(np.float32)
+    return (np.float32(0.5) * x * (np.float32(1.0) + erf(x * np.float32(0.7071067811865476)))
+            ).astype(np.float32)
+
+
+def attention(q, k, v, heads):
+    """q,k,v [N, H*64] float32 holding bf16 values (q pre-scaled by 1/8) -> [N, H*64] f32"""
+    n = q.shape[0]
+    out = np.empty_like(q)
+    for h in range(heads):
+        sl = slice(h * 64, (h + 1) * 64)
+        s = q[:, sl] @ k[:, sl].T
+        m = s.max(axis=1, keepdims=True)
+        p = np.exp(s - m, dtype=np.float32)
+        l = p.sum(axis=1, keepdims=True, dtype=np.float32)
+        out[:, sl] = (bf16r(p) @ v[:, sl]) / l
+    return out
+
+
+def im2col3x3(t, grid):
+    """t [grid*grid, C] -> [grid*grid, 9*C], column (ky*3+kx)*C + c, zero padding"""
+    c = t.shape[1]
+    g = np.zeros((grid + 2, grid + 2, c), np.float32)
+    g[1:-1, 1:-1] = t.reshape(grid, grid, c)
+    cols = [g[ky:ky + grid, kx:kx + grid].reshape(grid * grid, c)
+            for ky in range(3) for kx in range(3)]
+    return np.concatenate(cols, axis=1)
+
+
+class Model:
+    def __init__(self, blob_path_or_bytes):
+        import gstreamer_vit_tracker_amd.weights as W
+        if isinstance(blob_path_or_bytes, (bytes, bytearray, memoryview)):
+            raw = bytes(blob_path_or_bytes)
+        else:
+            with open(blob_path_or_bytes, "rb") as f:
+                raw = f.read()
+        self.hdr, tens = W.parse_blob(raw)
+        self.t = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32))
+                  for k, v in tens.items()}
+        h = self.hdr
+        self.patch, self.T, self.S, self.D = h["patch"], h["template"], h["search"], h["dim"]
+        self.H, self.L, self.kpad, self.C = h["heads"], h["layers"], h["kpad"], h["head_ch"]
+        self.gt, self.gs = self.T // self.patch, self.S // self.patch
+        self.nt, self.ns = self.gt ** 2, self.gs ** 2
+        self.eps = h["ln_eps"]
+
+    def forward(self, patches_bits, taps=False):
+        """patches_bits [N, kpad] uint16 (template rows then search rows) -> dict"""
+        t, D = self.t, self.D
+        out = {}
+        a = bf16_bits_to_f32(patches_bits)
+        x = a @ t["patch_w"].T + t["patch_b"] + t["pos"]
+        x = x.astype(np.float32)
+        if taps:
+            out["tokens0"] = x.copy()
+        for l in range(self.L):
+            p = f"l{l}."
+            h1 = bf16r(layernorm(x, t[p + "ln1_g"], t[p + "ln1_b"], self.eps))
+            qkv = (h1 @ t[p + "qkv_w"].T + t[p + "qkv_b"]).astype(np.float32)
+            q = bf16r(qkv[:, :D] * np.float32(0.125))
+            k = bf16r(qkv[:, D:2 * D])
+            v = bf16r(qkv[:, 2 * D:])
+            o = bf16r(attention(q, k, v, self.H))
+            x = (x + (o @ t[p + "proj_w"].T + t[p + "proj_b"])).astype(np.float32)
+            h2 = bf16r(layernorm(x, t[p + "ln2_g"], t[p + "ln2_b"], self.eps))
+            u = bf16r(gelu(h2 @ t[p + "fc1_w"].T + t[p + "fc1_b"]))
+            x = (x + (u @ t[p + "fc2_w"].T + t[p + "fc2_b"])).astype(np.float32)
+            if taps:
+                out[f"layer{l}"] = x.copy()
+        feat = bf16r(layernorm(x[self.nt:], t["norm_g"], t["norm_b"], self.eps))
+        out["feat"] = feat
+        out.update(self.head(feat))
+        return out
+
+    def head(self, feat):
+        t = self.t
+        relu = lambda z: np.maximum(z, np.float32(0.0)).astype(np.float32)
+        t0 = bf16r(relu(feat @ t["head.w0"].T + t["head.b0"]))
+        t1 = bf16r(relu(im2col3x3(t0, self.gs) @ t["head.w1"].T + t["head.b1"]))
+        t2 = bf16r(relu(im2col3x3(t1, self.gs) @ t["head.w2"].T + t["head.b2"]))
+        t3 = bf16r(relu(im2col3x3(t2, self.gs) @ t["head.w3"].T + t["head.b3"]))
+        o = (t3 @ t["head.w4"].T + t["head.b4"]).astype(np.float32)
+        return {"head_t3": t3, "head_out": o}
+
+
+class Result:
+    def __init__(self, success, score, bbox, fbox=None, idx=-1):
+        self.success, self.score, self.bbox, self.fbox, self.idx = success, score, bbox, fbox, idx
+
+    def __repr__(self):
+        return f"Result(success={self.success}, score={self.score:.4f}, bbox={self.bbox})"
+
+
+class VitTrackRef:
+    """≙ vit_tracker::VitTrack as the reference host uses it (src/tracker_context.rs:21,88,90)."""
+
+    def __init__(self, weights_path, success_threshold=None):
+        self.m = Model(weights_path)
+        self.thr = self.m.hdr["success_threshold"] if success_threshold is None \
+            else success_threshold
+        self.box = None          # float32 [x, y, w, h]
+        self.tpl = None          # template patch rows
+        self.last = {}
+
+    def _pre(self, frame, box, factor, size):
+        m = self.m
+        return preproc(frame, box, factor, size, m.patch, m.kpad, m.hdr["norm_a"],
+                       m.hdr["norm_b"])
+
+    def init(self, frame: Frame, bbox):
+        """≙ tracker.init(full_image, bbox) — return value unused by the caller (:88)"""
+        self.box = np.array([bbox[0], bbox[1], bbox[2], bbox[3]], np.float32)
+        self.tpl = self._pre(frame, self.box, 2.0, self.m.T)
+
+    def update(self, frame: Frame, taps=False) -> Result:
+        """≙ tracker.update(full_image) -> {success, score, bbox} (:90,120)"""
+        if self.box is None:
+            raise RuntimeError("update before init")
+        m = self.m
+        geo = crop_geometry(self.box, 4.0, m.S)
+        srch = self._pre(frame, self.box, 4.0, m.S)
+        patches = np.concatenate([self.tpl, srch], axis=0)
+        out = m.forward(patches, taps=taps)
+        ho = np.ascontiguousarray(out["head_out"], np.float32)
+        hann = np.ascontiguousarray(m.t["hann"].reshape(-1), np.float32)
+        dec = np.zeros(6, np.float32)
+        ib = np.zeros(4, np.int32)
+        lib().vto_decode(_fp(ho), _fp(hann), m.gs, _fp(geo), frame.w, frame.h, _fp(dec),
+                         ib.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        score = float(dec[0])
+        success = bool(score >= self.thr)
+        if success:
+            self.box = dec[1:5].astype(np.float32).copy()
+        if taps:
+            out["patches"] = patches
+            out["geo"] = geo
+            self.last = out
+        return Result(success, score, tuple(int(v) for v in ib), dec[1:5].copy(), int(dec[5]))

@@ -1,0 +1,292 @@
+/*
+ * vt_oracle.c — CPU restatement (plain C) of the integer / byte stages of the tracker hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under gstreamer-vit-tracker_amd/ may link, import or call
+ * this file; it is the checker for the HIP path (tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py).
+ *
+ * PARITY STATUS
+ *   - NV12 -> RGB8 (vto_nv12_to_rgb8): restates /root/reference/src/nv12_convert.rs:8-169 line by
+ *     line. The reference holds no tests or golden vectors, and its Rust
+ *     toolchain is absent here, so this stage is pinned only by known-answer vectors derived by
+ *     hand from the formulas at src/nv12_convert.rs:24-29,124-126 (tests/golden/nv12_kat.json).
+ *   - crop / resize / normalise (vto_preproc_*): the reference's implementation lives in the
+ *     un-vendored path crate `vit_tracker 0.1.0` (Cargo.toml:24, Cargo.lock:1145-1155), which is
+ *     not available. The algorithm below is this build's own specification.
+ *     PARITY UNPINNED against the reference for this stage.
+ *
+ * Floating point: every float operation here is a single IEEE-754 binary32 operation; compile
+ * with -ffp-contract=off so that no FMA is formed. The HIP kernel uses the same operations in the
+ * same order (__fmul_rn/__fadd_rn), so the two agree bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * NV12 -> RGB8   (reference: src/nv12_convert.rs)
+ * ------------------------------------------------------------------------------------------- */
+
+/* src/nv12_convert.rs:8-34  YuvTables::new — five 256-entry i32 tables */
+typedef struct {
+    int32_t y_table[256];  /* 298 * (y - 16)  */
+    int32_t rv_table[256]; /* 409 * (v - 128) */
+    int32_t gu_table[256]; /* 100 * (u - 128) */
+    int32_t gv_table[256]; /* 208 * (v - 128) */
+    int32_t bu_table[256]; /* 516 * (u - 128) */
+} yuv_tables;
+
+static yuv_tables g_tables;
+static int g_tables_ready = 0;
+
+/* src/nv12_convert.rs:36-38  get_tables (OnceLock) */
+static const yuv_tables* get_tables(void) {
+    if (!g_tables_ready) {
+        for (int i = 0; i < 256; ++i) {
+            g_tables.y_table[i] = 298 * (i - 16);
+            g_tables.rv_table[i] = 409 * (i - 128);
+            g_tables.gu_table[i] = 100 * (i - 128);
+            g_tables.gv_table[i] = 208 * (i - 128);
+            g_tables.bu_table[i] = 516 * (i - 128);
+        }
+        g_tables_ready = 1;
+    }
+    return &g_tables;
+}
+
+/* src/nv12_convert.rs:41-43  clamp_u8 */
+static inline uint8_t clamp_u8(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v); }
+
+/* One pixel: src/nv12_convert.rs:124-131. `>>` on a negative i32 is an arithmetic shift in Rust;
+ * gcc implements signed >> as arithmetic as well (implementation-defined, documented). */
+void vto_yuv_to_rgb_px(uint8_t y, uint8_t u, uint8_t v, uint8_t* rgb) {
+    const yuv_tables* t = get_tables();
+    int32_t yv = t->y_table[y];
+    rgb[0] = clamp_u8((yv + t->rv_table[v] + 128) >> 8);
+    rgb[1] = clamp_u8((yv - t->gu_table[u] - t->gv_table[v] + 128) >> 8);
+    rgb[2] = clamp_u8((yv + t->bu_table[u] + 128) >> 8);
+}
+
+/* src/nv12_convert.rs:95-169  process_row_unsafe: one output row from one Y row and one UV row */
+static void process_row(const uint8_t* y_plane, const uint8_t* uv_plane, uint8_t* row_data,
+                        size_t row, size_t uv_row, size_t width, const yuv_tables* t) {
+    size_t y_row_start = row * width;
+    size_t uv_row_start = uv_row * width; /* :106 stride == width */
+    size_t col = 0;
+    while (col + 1 < width) { /* :109 two pixels share one UV pair */
+        size_t uv_idx = uv_row_start + col;
+        uint8_t u = uv_plane[uv_idx], v = uv_plane[uv_idx + 1];
+        int32_t rv = t->rv_table[v], gu = t->gu_table[u], gv = t->gv_table[v],
+                bu = t->bu_table[u];
+        int32_t y0 = t->y_table[y_plane[y_row_start + col]];
+        row_data[col * 3 + 0] = clamp_u8((y0 + rv + 128) >> 8);
+        row_data[col * 3 + 1] = clamp_u8((y0 - gu - gv + 128) >> 8);
+        row_data[col * 3 + 2] = clamp_u8((y0 + bu + 128) >> 8);
+        int32_t y1 = t->y_table[y_plane[y_row_start + col + 1]];
+        row_data[(col + 1) * 3 + 0] = clamp_u8((y1 + rv + 128) >> 8);
+        row_data[(col + 1) * 3 + 1] = clamp_u8((y1 - gu - gv + 128) >> 8);
+        row_data[(col + 1) * 3 + 2] = clamp_u8((y1 + bu + 128) >> 8);
+        col += 2;
+    }
+    if (col < width) { /* :150 odd-width tail */
+        size_t uv_idx = uv_row_start + (col / 2) * 2;
+        uint8_t u = uv_plane[uv_idx], v = uv_plane[uv_idx + 1];
+        int32_t y0 = t->y_table[y_plane[y_row_start + col]];
+        row_data[col * 3 + 0] = clamp_u8((y0 + t->rv_table[v] + 128) >> 8);
+        row_data[col * 3 + 1] = clamp_u8((y0 - t->gu_table[u] - t->gv_table[v] + 128) >> 8);
+        row_data[col * 3 + 2] = clamp_u8((y0 + t->bu_table[u] + 128) >> 8);
+    }
+}
+
+/* Bytes of the packed buffer the reference actually reads (it only checks len >= w*h*3/2,
+ * src/nv12_convert.rs:48; for odd w/h it reads further, which is UB there). */
+size_t vto_nv12_bytes_read(size_t width, size_t height) {
+    size_t uv_rows = (height + 1) / 2;
+    if (width == 0 || height == 0) return 0;
+    /* last UV read: uv_row*(width) + (width even ? width-1 : (width-1)+1) */
+    size_t last = (uv_rows - 1) * width + ((width & 1) ? width : width - 1);
+    return width * height + last + 1;
+}
+
+/* src/nv12_convert.rs:46-92  nv12_full_to_rgb_parallel.
+ * returns 0 = converted, 1 = short buffer -> all-zero frame (:48-50),
+ * -1 = len >= w*h*3/2 but shorter than what the reference would read (UB in the reference). */
+int vto_nv12_to_rgb8(const uint8_t* nv12, size_t len, size_t width, size_t height, uint8_t* out,
+                     int nthreads) {
+    size_t y_plane_size = width * height;
+    if (len < y_plane_size * 3 / 2) {
+        memset(out, 0, height * width * 3);
+        return 1;
+    }
+    if (len < vto_nv12_bytes_read(width, height)) return -1;
+    const yuv_tables* t = get_tables();
+    const uint8_t* y_plane = nv12;
+    const uint8_t* uv_plane = nv12 + y_plane_size;
+    long pairs = (long)((height + 1) / 2); /* :59 par_chunks_mut(width*3*2) */
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (long pair_idx = 0; pair_idx < pairs; ++pair_idx) {
+        size_t row0 = (size_t)pair_idx * 2, row1 = row0 + 1, uv_row = (size_t)pair_idx;
+        process_row(y_plane, uv_plane, out + row0 * width * 3, row0, uv_row, width, t);
+        if (row1 < height) /* :67 last odd row has no partner */
+            process_row(y_plane, uv_plane, out + row1 * width * 3, row1, uv_row, width, t);
+    }
+    (void)nthreads;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * crop + bilinear resize + normalise -> bf16 patch matrix   (build specification)
+ * ------------------------------------------------------------------------------------------- */
+
+/* float32 -> bfloat16 bits, round to nearest even (inputs are finite here) */
+uint16_t vto_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); /* NaN stays NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float vto_bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* crop window of a float box {x, y, w, h} (top-left + size, frame pixels):
+ *   side  = factor * sqrtf(w*h)          (continuous; factor 2 template, 4 search)
+ *   scale = side / out_size
+ *   x0m   = (x + 0.5*w) - 0.5*side - 0.5   (so that src_x = x0m + (ox + 0.5)*scale)
+ * geo[0..3] = {x0m, y0m, scale, side} */
+void vto_crop_geometry(const float* box, float factor, int out_size, float* geo) {
+    float area = box[2] * box[3];
+    float side = factor * sqrtf(area);
+    float scale = side / (float)out_size;
+    float cx = box[0] + 0.5f * box[2];
+    float cy = box[1] + 0.5f * box[3];
+    float half = 0.5f * side;
+    geo[0] = (cx - half) - 0.5f;
+    geo[1] = (cy - half) - 0.5f;
+    geo[2] = scale;
+    geo[3] = side;
+}
+
+typedef struct {
+    const uint8_t* p0; /* RGB8 packed or Y plane */
+    const uint8_t* p1; /* UV plane (NV12) */
+    int w, h, s0, s1, fmt; /* fmt 0 = RGB8, 1 = NV12 */
+} vto_frame;
+
+/* pixel (px,py) of the frame as RGB; outside the frame -> (0,0,0) */
+static inline void fetch_rgb(const vto_frame* f, int px, int py, float* rgb) {
+    if (px < 0 || py < 0 || px >= f->w || py >= f->h) {
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        return;
+    }
+    uint8_t c[3];
+    if (f->fmt == 0) {
+        const uint8_t* p = f->p0 + (size_t)py * f->s0 + (size_t)px * 3;
+        c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
+    } else {
+        /* same addressing as src/nv12_convert.rs:111-113,152: UV pair of column (px & ~1),
+         * UV row py/2 */
+        uint8_t yy = f->p0[(size_t)py * f->s0 + px];
+        const uint8_t* uvp = f->p1 + (size_t)(py >> 1) * f->s1 + (px & ~1);
+        vto_yuv_to_rgb_px(yy, uvp[0], uvp[1], c);
+    }
+    rgb[0] = (float)c[0]; rgb[1] = (float)c[1]; rgb[2] = (float)c[2];
+}
+
+/* Writes the patch matrix of one crop: rows = (out_size/patch)^2 tokens (row-major over the
+ * token grid), kpad columns of bf16; column k = c*patch*patch + py*patch + px, columns
+ * >= 3*patch*patch are zero. norm_a/norm_b: out = v*norm_a[c] + norm_b[c]. */
+void vto_preproc(const uint8_t* p0, const uint8_t* p1, int w, int h, int s0, int s1, int fmt,
+                 const float* box, float factor, int out_size, int patch, int kpad,
+                 const float* norm_a, const float* norm_b, uint16_t* out_rows) {
+    vto_frame f = {p0, p1, w, h, s0, s1, fmt};
+    float geo[4];
+    vto_crop_geometry(box, factor, out_size, geo);
+    const float x0m = geo[0], y0m = geo[1], scale = geo[2];
+    const int grid = out_size / patch;
+    memset(out_rows, 0, (size_t)grid * grid * kpad * sizeof(uint16_t));
+    for (int oy = 0; oy < out_size; ++oy) {
+        float fy = ((float)oy + 0.5f) * scale + y0m;
+        float fy0 = floorf(fy);
+        float wy = fy - fy0;
+        int iy = (int)fy0;
+        for (int ox = 0; ox < out_size; ++ox) {
+            float fx = ((float)ox + 0.5f) * scale + x0m;
+            float fx0 = floorf(fx);
+            float wx = fx - fx0;
+            int ix = (int)fx0;
+            float p00[3], p01[3], p10[3], p11[3];
+            fetch_rgb(&f, ix, iy, p00);
+            fetch_rgb(&f, ix + 1, iy, p01);
+            fetch_rgb(&f, ix, iy + 1, p10);
+            fetch_rgb(&f, ix + 1, iy + 1, p11);
+            int token = (oy / patch) * grid + (ox / patch);
+            int kin = (oy % patch) * patch + (ox % patch);
+            for (int c = 0; c < 3; ++c) {
+                float top = p00[c] + wx * (p01[c] - p00[c]);
+                float bot = p10[c] + wx * (p11[c] - p10[c]);
+                float v = top + wy * (bot - top);
+                float o = v * norm_a[c] + norm_b[c];
+                out_rows[(size_t)token * kpad + c * patch * patch + kin] = vto_f32_to_bf16(o);
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * box decode (build specification): one place for the float op order
+ * ------------------------------------------------------------------------------------------- */
+
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* head_out: [grid*grid][8] logits (score, ox, oy, w, h, -, -, -); hann: [grid*grid];
+ * geo: search-crop geometry {x0m, y0m, scale, side}; out: {score, X1, Y1, W, H, idx} floats
+ * (clipped float box in frame pixels), ibox: rounded integer box */
+void vto_decode(const float* head_out, const float* hann, int grid, const float* geo, int frame_w,
+                int frame_h, float* out, int32_t* ibox) {
+    int n = grid * grid, best = 0;
+    float best_resp = -1.0f;
+    for (int i = 0; i < n; ++i) {
+        float s = sigmoidf_(head_out[i * 8 + 0]);
+        float r = s * hann[i];
+        if (r > best_resp) { best_resp = r; best = i; }
+    }
+    const float* o = head_out + best * 8;
+    float score = sigmoidf_(o[0]);
+    float offx = sigmoidf_(o[1]), offy = sigmoidf_(o[2]);
+    float wn = sigmoidf_(o[3]), hn = sigmoidf_(o[4]);
+    int ix = best % grid, iy = best / grid;
+    float side = geo[3];
+    float cxn = ((float)ix + offx) / (float)grid;
+    float cyn = ((float)iy + offy) / (float)grid;
+    /* crop origin in frame pixels = x0m + 0.5 */
+    float cx = (geo[0] + 0.5f) + cxn * side;
+    float cy = (geo[1] + 0.5f) + cyn * side;
+    float bw = wn * side, bh = hn * side;
+    float x1 = cx - 0.5f * bw, y1 = cy - 0.5f * bh;
+    float x2 = x1 + bw, y2 = y1 + bh;
+    const float margin = 10.0f;
+    float W = (float)frame_w, H = (float)frame_h;
+    x1 = fminf(fmaxf(0.0f, x1), W - margin);
+    y1 = fminf(fmaxf(0.0f, y1), H - margin);
+    x2 = fminf(fmaxf(margin, x2), W);
+    y2 = fminf(fmaxf(margin, y2), H);
+    bw = fmaxf(margin, x2 - x1);
+    bh = fmaxf(margin, y2 - y1);
+    out[0] = score; out[1] = x1; out[2] = y1; out[3] = bw; out[4] = bh; out[5] = (float)best;
+    ibox[0] = (int32_t)floorf(x1 + 0.5f);
+    ibox[1] = (int32_t)floorf(y1 + 0.5f);
+    ibox[2] = (int32_t)floorf(bw + 0.5f);
+    ibox[3] = (int32_t)floorf(bh + 0.5f);
+}

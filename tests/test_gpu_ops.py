@@ -1,0 +1,152 @@
+"""Operator-level numerics: each HIP kernel against a plain float32 NumPy reference of the same op
+(bf16 operands are exact in float32, accumulation in float32). Calls go through the C ABI."""
+import numpy as np
+import pytest
+from scipy.special import erf
+
+from conftest import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(vt, x):
+    return vt.weights.f32_to_bf16_bits(np.asarray(x, np.float32))
+
+
+def _rand_bf16(vt, rng, shape, scale=1.0):
+    x = (rng.standard_normal(shape) * scale).astype(np.float32)
+    b = _bits(vt, x)
+    return b, vt.weights.bf16_bits_to_f32(b)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (80, 128, 128), (320, 768, 768), (720, 2304, 768),
+                                   (1, 64, 192), (257, 192, 3072), (2880, 768, 768)])
+def test_gemm_f32(gpu, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.05)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = a @ w.T + bias
+    got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0)
+    tol = 1e-4 * np.sqrt(K) * np.abs(ref).max() / 10 + 1e-4
+    assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
+
+
+def test_gemm_exact_integers_asymmetric(gpu):
+    """A = identity-like selector, W asymmetric small integers: catches swapped row/col maps and
+    any staging/swizzle mix-up exactly (all values are exact in bf16 and f32)."""
+    M, N, K = 128, 128, 128
+    a = np.zeros((M, K), np.float32)
+    a[np.arange(M), np.arange(M) % K] = 1.0
+    a[np.arange(M), (np.arange(M) * 5 + 3) % K] += 2.0
+    w = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 7) % 17 - 8).astype(np.float32)
+    ref = a @ w.T
+    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), None, epilogue=0)
+    assert np.array_equal(got, ref)
+
+
+def test_gemm_residual(gpu):
+    rng = np.random.default_rng(5)
+    M, N, K = 320, 768, 3072
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.02)
+    bias = rng.standard_normal(N).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = c0 + a @ w.T + bias
+    got = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=1)
+    assert np.abs(got - ref).max() < 2e-3
+
+
+@pytest.mark.parametrize("epi", [2, 3])
+def test_gemm_activation_bf16(gpu, epi):
+    rng = np.random.default_rng(11 + epi)
+    M, N, K = 336, 512, 768
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.05)
+    bias = rng.standard_normal(N).astype(np.float32)
+    z = a @ w.T + bias
+    if epi == 2:
+        ref = 0.5 * z * (1.0 + erf(z * 0.7071067811865476))
+    else:
+        ref = np.maximum(z, 0)
+    got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=epi)
+    # output is bf16: half an ulp (2^-9 relative) plus accumulation noise
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
+    assert np.array_equal(got, bf16_round(got))
+
+
+@pytest.mark.parametrize("B,tokens,D", [(1, 80, 128), (2, 320, 768), (1, 720, 768)])
+def test_qkv_epilogue_layout(gpu, B, tokens, D):
+    rng = np.random.default_rng(B * 100 + tokens)
+    M = B * tokens
+    ab, a = _rand_bf16(gpu, rng, (M, D))
+    wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
+    bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
+    z = a @ w.T + bias
+    qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
+    ref_qk = np.concatenate([z[:, :D] * 0.125, z[:, D:2 * D]], axis=1)
+    assert np.all(np.abs(qk - ref_qk) <= np.abs(ref_qk) * 2 ** -8 + 1e-3)
+    H = D // 64
+    v = z[:, 2 * D:].reshape(B, tokens, H, 64).transpose(0, 2, 3, 1).reshape(B * H, 64, tokens)
+    assert np.all(np.abs(vt_[:, :, :tokens] - v) <= np.abs(v) * 2 ** -8 + 1e-3)
+    assert np.all(vt_[:, :, tokens:] == 0)
+
+
+def _attn_ref(q, k, v, B, N, H):
+    out = np.zeros((B * N, H * 64), np.float32)
+    for b in range(B):
+        for h in range(H):
+            sl = slice(h * 64, (h + 1) * 64)
+            rows = slice(b * N, (b + 1) * N)
+            s = q[rows, sl] @ k[rows, sl].T
+            p = np.exp(s - s.max(axis=1, keepdims=True))
+            out[rows, sl] = (p @ v[rows, sl]) / p.sum(axis=1, keepdims=True)
+    return out
+
+
+@pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0),
+                                         (1, 980, 16, 0.5), (1, 33, 1, 3.0)])
+def test_attention(gpu, B, N, H, scale):
+    rng = np.random.default_rng(N + H)
+    D = H * 64
+    qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
+    kb, k = _rand_bf16(gpu, rng, (B * N, D), scale)
+    vb, v = _rand_bf16(gpu, rng, (B * N, D))
+    ref = _attn_ref(q, k, v, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    err = np.abs(got - ref)
+    # P is rounded to bf16 before the PV product and the output is bf16
+    assert err.max() < 0.02 * max(1.0, np.abs(ref).max()), err.max()
+    assert err.mean() < 2e-3
+
+
+def test_attention_exact_selector(gpu):
+    """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
+    bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
+    N, H = 96, 1
+    q = np.zeros((N, 64), np.float32)
+    k = np.zeros((N, 64), np.float32)
+    sel = (np.arange(N) * 37 + 5) % N
+    for i in range(N):
+        k[i, i % 64] = 8.0
+        k[i, (i // 64) + 40] += 8.0
+    for i in range(N):
+        j = sel[i]
+        q[i, j % 64] = 4.0
+        q[i, (j // 64) + 40] += 4.0
+    v = ((np.arange(N)[:, None] * 5 + np.arange(64)[None, :] * 3) % 31 - 15).astype(np.float32)
+    got = gpu.op_attention_bf16(_bits(gpu, q), _bits(gpu, k), _bits(gpu, v), 1, N, H)
+    assert np.abs(got - v[sel]).max() < 1e-3
+
+
+@pytest.mark.parametrize("M,D", [(80, 128), (720, 768), (100, 1024)])
+def test_layernorm(gpu, M, D):
+    rng = np.random.default_rng(M + D)
+    x = (rng.standard_normal((M, D)) * 2 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    ref = (x - mean) / np.sqrt(var + 1e-6) * g + b
+    got = gpu.op_layernorm(x, g, b)
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-4)

@@ -1,0 +1,226 @@
+"""Parity of the HIP hot path against the CPU oracle, through the C ABI, on the same seeded inputs.
+
+Bars: integer / byte stages bit-exact (NV12->RGB8, and the patch matrix produced
+by crop+resize+normalise, whose float ops are single IEEE operations in a fixed order); network
+tensors within bf16 tolerances; boxes within +-1 px of the oracle's, mean IoU >= 0.99.
+"""
+import numpy as np
+import pytest
+
+from conftest import iou
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- stage (a): the reference's colour converter, bit-exact ----------------------------------
+
+@pytest.mark.parametrize("w,h", [(64, 48), (640, 480), (1920, 1080), (66, 50), (31, 17), (33, 16)])
+def test_nv12_full_frame_bit_exact(gpu, oracle, w, h):
+    rng = np.random.default_rng(w * h)
+    n = w * h + w * ((h + 1) // 2) + 2
+    buf = rng.integers(0, 256, n, dtype=np.uint8)
+    ref, st = oracle.nv12_to_rgb8(buf, w, h, 4)
+    assert st == 0
+    got = gpu.nv12_full_to_rgb(buf, w, h)
+    assert np.array_equal(got, ref)
+
+
+def test_nv12_short_buffer_gives_zero_frame(gpu, oracle):
+    w, h = 64, 48
+    buf = np.full(w * h * 3 // 2 - 1, 200, np.uint8)
+    ref, st = oracle.nv12_to_rgb8(buf, w, h, 1)
+    assert st == 1 and not ref.any()
+    got = gpu.nv12_full_to_rgb(buf, w, h)
+    assert not got.any()
+
+
+def test_nv12_full_frame_synthetic_1080p(gpu, oracle):
+    sc = gpu.synth.MovingSquare(1920, 1080, 64, seed=0)
+    buf = sc.frame_nv12(3)
+    ref, _ = oracle.nv12_to_rgb8(buf, 1920, 1080, 8)
+    assert np.array_equal(gpu.nv12_full_to_rgb(buf, 1920, 1080), ref)
+    assert np.array_equal(ref, sc.frame_rgb8(3))
+
+
+# ---- stage (b): crop + resize + normalise -> patch matrix, bit-exact ---------------------------
+
+def _patches_case(gpu, oracle, weights, frame_np, oframe, box):
+    trk = gpu.VitTrack.new(weights)
+    ref = oracle.VitTrackRef(weights)
+    trk.init(frame_np, gpu.BBox.new(*box))
+    ref.init(oframe, box)
+    r_gpu = trk.update(frame_np)
+    r_ref = ref.update(oframe, taps=True)
+    g = trk.as_group()
+    mi = trk.model_info()
+    got = g.read_tensor("patches").reshape(mi.tokens_template + mi.tokens_search, mi.kpad)
+    want = oracle.bf16_bits_to_f32(ref.last["patches"])
+    return got, want, r_gpu, r_ref
+
+
+@pytest.mark.parametrize("box", [(288, 208, 64, 64), (300, 200, 41, 77), (5, 3, 50, 40),
+                                 (600, 440, 30, 30), (100, 100, 333, 201)])
+def test_patch_matrix_bit_exact_nv12(gpu, oracle, weights_tiny, box):
+    sc = gpu.synth.MovingSquare(640, 480, 64, seed=1)
+    buf = sc.frame_nv12(0)
+    got, want, _, _ = _patches_case(gpu, oracle, weights_tiny, gpu.NV12Frame(buf, 640, 480),
+                                    oracle.Frame.nv12(buf, 640, 480), box)
+    assert np.array_equal(got, want)
+
+
+def test_patch_matrix_bit_exact_rgb8(gpu, oracle, weights_tiny):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    got, want, _, _ = _patches_case(gpu, oracle, weights_tiny, img, oracle.Frame.rgb8(img),
+                                    (250, 190, 90, 60))
+    assert np.array_equal(got, want)
+
+
+# ---- stage (c): the network, per-stage tolerances ------------------------------------------------
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "cfg2"])
+def test_network_stage_taps(gpu, oracle, cfg):
+    weights = gpu.weights.ensure_weights(cfg)
+    sc = gpu.synth.MovingSquare(640, 480, 64, seed=2)
+    buf = sc.frame_nv12(0)
+    box = sc.gt_box(0)
+    trk = gpu.VitTrack.new(weights)
+    g = trk.as_group()
+    g.enable_taps(True)
+    ref = oracle.VitTrackRef(weights)
+    f = gpu.NV12Frame(buf, 640, 480)
+    of = oracle.Frame.nv12(buf, 640, 480)
+    trk.init(f, gpu.BBox.new(*box))
+    ref.init(of, box)
+    r_gpu = trk.update(f)
+    r_ref = ref.update(of, taps=True)
+    mi = trk.model_info()
+    n, d = mi.tokens_template + mi.tokens_search, mi.dim
+    assert np.array_equal(g.read_tensor("patches").reshape(n, mi.kpad),
+                          oracle.bf16_bits_to_f32(ref.last["patches"]))
+    tok0 = g.read_tensor("tokens0").reshape(n, d)
+    assert _rel(tok0, ref.last["tokens0"]) < 1e-5
+    for l in range(mi.layers):
+        x = g.read_tensor(f"layer{l}").reshape(n, d)
+        assert _rel(x, ref.last[f"layer{l}"]) < 2e-2, f"layer {l}"
+    feat = g.read_tensor("feat").reshape(mi.tokens_search, d)
+    assert _rel(feat, ref.last["feat"]) < 3e-2
+    ho = g.read_tensor("head_out").reshape(mi.tokens_search, 8)
+    assert np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() < 0.05 * max(
+        1.0, np.abs(ref.last["head_out"]).max())
+    assert abs(r_gpu.score - r_ref.score) < 0.02
+    g.enable_taps(False)
+
+
+# ---- stage (d): closed-loop trajectories ------------------------------------------------------------
+
+def _run_pair(gpu, oracle, weights, sc, frames, use_nv12=True, use_graph=True):
+    w, h = sc.w, sc.h
+    trk = gpu.VitTrack(weights, use_graph=use_graph)
+    ref = oracle.VitTrackRef(weights)
+    boxes_g, boxes_r, scores = [], [], []
+    for t in range(frames):
+        if use_nv12:
+            buf = sc.frame_nv12(t)
+            f, of = gpu.NV12Frame(buf, w, h), oracle.Frame.nv12(buf, w, h)
+        else:
+            img = sc.frame_rgb8(t)
+            f, of = img, oracle.Frame.rgb8(img)
+        if t == 0:
+            # the reference host inits then updates on the SAME frame (tracker_context.rs:88-90)
+            trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
+            ref.init(of, sc.gt_box(0))
+        rg, rr = trk.update(f), ref.update(of)
+        boxes_g.append(tuple(rg.bbox))
+        boxes_r.append(tuple(rr.bbox))
+        scores.append((rg.score, rr.score, rg.success, rr.success))
+    return boxes_g, boxes_r, scores
+
+
+def _assert_parity(sc, boxes_g, boxes_r, scores, min_gt_iou=0.5):
+    d = np.abs(np.array(boxes_g) - np.array(boxes_r))
+    ious = [iou(a, b) for a, b in zip(boxes_g, boxes_r)]
+    gt_iou = [iou(a, sc.gt_box(t)) for t, a in enumerate(boxes_r)]
+    assert d.max() <= 1, f"max |delta| = {d.max()} px at frame {int(d.max(axis=1).argmax())}"
+    assert np.mean(ious) >= 0.99, f"mean IoU(hip, oracle) = {np.mean(ious):.4f}"
+    assert all(s[2] == s[3] for s in scores), "success flags differ"
+    assert max(abs(s[0] - s[1]) for s in scores) < 0.03
+    # the fitted head really follows the square (otherwise the parity above would be vacuous)
+    assert min(gt_iou) > min_gt_iou, f"oracle lost the target: min IoU vs GT {min(gt_iou):.3f}"
+
+
+def test_trajectory_cfg1_rgb_640x480(gpu, oracle, weights_tiny):
+    sc = gpu.synth.MovingSquare(640, 480, 64, seed=0)
+    bg, br, s = _run_pair(gpu, oracle, weights_tiny, sc, 300, use_nv12=False)
+    _assert_parity(sc, bg, br, s)
+
+
+def test_trajectory_cfg2_nv12_1080p_300_frames(gpu, oracle, weights_cfg2):
+    sc = gpu.synth.MovingSquare(1920, 1080, 64, seed=0)
+    bg, br, s = _run_pair(gpu, oracle, weights_cfg2, sc, 300)
+    _assert_parity(sc, bg, br, s)
+
+
+def test_trajectory_cfg3_nv12_1080p(gpu, oracle, weights_cfg3):
+    sc = gpu.synth.MovingSquare(1920, 1080, 64, seed=1)
+    bg, br, s = _run_pair(gpu, oracle, weights_cfg3, sc, 60)
+    _assert_parity(sc, bg, br, s)
+
+
+def test_graph_and_eager_agree(gpu, weights_tiny):
+    sc = gpu.synth.MovingSquare(640, 480, 64, seed=4)
+    out = []
+    for use_graph in (True, False):
+        trk = gpu.VitTrack(weights_tiny, use_graph=use_graph)
+        boxes = []
+        for t in range(20):
+            f = gpu.NV12Frame(sc.frame_nv12(t), 640, 480)
+            if t == 0:
+                trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
+            r = trk.update(f)
+            boxes.append((tuple(r.bbox), r.score))
+        out.append(boxes)
+    assert out[0] == out[1]
+
+
+def test_group_streams_are_independent(gpu, weights_tiny):
+    """B streams batched in one pass give exactly what B single trackers give."""
+    import torch
+    B, w, h = 3, 640, 480
+    scs = [gpu.synth.MovingSquare(w, h, 64, seed=10 + i) for i in range(B)]
+    grp = gpu.Group(weights_tiny, n_streams=B)
+    singles = [gpu.VitTrack(weights_tiny) for _ in range(B)]
+    for t in range(8):
+        bufs = [torch.from_numpy(sc.frame_nv12(t)).cuda() for sc in scs]
+        frames = [gpu.frame_nv12(b.data_ptr(), b.data_ptr() + w * h, w, h) for b in bufs]
+        if t == 0:
+            for i in range(B):
+                grp.init_device(i, frames[i], gpu.BBox.new(*scs[i].gt_box(0)))
+                singles[i].init(gpu.NV12Frame(scs[i].frame_nv12(0), w, h),
+                                gpu.BBox.new(*scs[i].gt_box(0)))
+        res = grp.update_device(frames)
+        for i in range(B):
+            r1 = singles[i].update(gpu.NV12Frame(scs[i].frame_nv12(t), w, h))
+            assert res[i].bbox == r1.bbox and abs(res[i].score - r1.score) < 1e-6
+    st = grp.read_state(1)
+    assert st["frames_done"] == 8
+
+
+def test_errors_do_not_abort(gpu, weights_tiny, tmp_path):
+    with pytest.raises(gpu.VtError):
+        gpu.VitTrack.new(str(tmp_path / "missing.vtw"))
+    bad = tmp_path / "bad.vtw"
+    bad.write_bytes(b"NOTAVTWB" + b"\0" * 1000)
+    with pytest.raises(gpu.VtError):
+        gpu.VitTrack.new(str(bad))
+    trk = gpu.VitTrack.new(weights_tiny)
+    img = np.zeros((480, 640, 3), np.uint8)
+    with pytest.raises(gpu.VtError) as e:
+        trk.update(img)          # update before init
+    assert e.value.code == -6
+    with pytest.raises(gpu.VtError):
+        trk.init(img, gpu.BBox.new(10, 10, 0, 5))
