@@ -89,6 +89,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise VtError(-2, f"{LIB_PATH} not built: run `python __graft_entry__.py` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64 and a
+    # second copy loaded later cannot see the GPU ("No HIP GPUs are available"). Importing torch
+    # first makes this library's DT_NEEDED libamdhip64.so.7 resolve to the copy already loaded.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent: the library brings in /opt/rocm's runtime itself
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.vt_last_error.restype = c_char_p
     L.vt_config_default.argtypes = [POINTER(CConfig)]

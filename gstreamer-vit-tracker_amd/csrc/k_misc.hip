@@ -156,15 +156,31 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     if (tid != 0) return;
     StreamState& s = a.states[b];
     const int idx = s_idx[0];
-    const float* o = s_logit[idx & 255];  // cell i is handled by thread i % 256
-    const float score = sigmoidf_(o[0]);
-    const float offx = sigmoidf_(o[1]), offy = sigmoidf_(o[2]);
-    const float wn = sigmoidf_(o[3]), hn = sigmoidf_(o[4]);
+    const float score = sigmoidf_(s_logit[idx & 255][0]);  // cell i is handled by thread i % 256
     const int grid = a.grid;
-    const int ix = idx % grid, iy = idx / grid;
+    const int bx = idx % grid, by = idx / grid;
+    // response^2-weighted mean over the 3x3 window around the argmax (see vto_decode). The other
+    // threads' head_out rows were written before the barriers above (same workgroup, same CU).
+    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = bx + dx, iy = by + dy;
+            if (ix < 0 || iy < 0 || ix >= grid || iy >= grid) continue;
+            const float* o = a.head_out + ((size_t)b * ns + iy * grid + ix) * 8;
+            const float r = sigmoidf_(o[0]) * a.hann[iy * grid + ix];
+            const float w = r * r;
+            const float offx = 3.0f * sigmoidf_(o[1]) - 1.0f;
+            const float offy = 3.0f * sigmoidf_(o[2]) - 1.0f;
+            const float cxj = ((float)ix + offx) / (float)grid;
+            const float cyj = ((float)iy + offy) / (float)grid;
+            sw = sw + w;
+            scx = scx + w * cxj;
+            scy = scy + w * cyj;
+            sbw = sbw + w * sigmoidf_(o[3]);
+            sbh = sbh + w * sigmoidf_(o[4]);
+        }
+    const float cxn = scx / sw, cyn = scy / sw, wn = sbw / sw, hn = sbh / sw;
     const float side = s.geo[3];
-    const float cxn = ((float)ix + offx) / (float)grid;
-    const float cyn = ((float)iy + offy) / (float)grid;
     const float cx = (s.geo[0] + 0.5f) + cxn * side;
     const float cy = (s.geo[1] + 0.5f) + cyn * side;
     float bw = wn * side, bh = hn * side;

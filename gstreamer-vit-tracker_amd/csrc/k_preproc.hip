@@ -18,12 +18,16 @@
 // /root/reference/src/nv12_convert.rs:24-29 (table entries) and :124-131 (per pixel)
 __device__ __forceinline__ void yuv_to_rgb(int y, int u, int v, int& r, int& g, int& b) {
     const int yv = 298 * (y - 16);
-    r = (yv + 409 * (v - 128) + 128) >> 8;
-    g = (yv - 100 * (u - 128) - 208 * (v - 128) + 128) >> 8;
-    b = (yv + 516 * (u - 128) + 128) >> 8;
-    r = min(max(r, 0), 255);
-    g = min(max(g, 0), 255);
-    b = min(max(b, 0), 255);
+    r = yv + 409 * (v - 128) + 128;
+    g = yv - 100 * (u - 128) - 208 * (v - 128) + 128;
+    b = yv + 516 * (u - 128) + 128;
+    // clamp_u8(x >> 8) written as clamp first, shift second (same value: the arithmetic shift is
+    // monotonic). The shift-then-clamp form is pattern-matched by hipcc (ROCm 7.2) into
+    // v_ashr_pk_u8_i32, whose upper 16 result bits are not zero on MI355X although the
+    // compiler ORs the result as if they were — measured: wrong bytes 2/3 of every packed dword.
+    r = min(max(r, 0), 0xffff) >> 8;
+    g = min(max(g, 0), 0xffff) >> 8;
+    b = min(max(b, 0), 0xffff) >> 8;
 }
 
 // One lane converts 4 horizontally adjacent pixels (two UV pairs). Packed NV12, stride == width

@@ -252,7 +252,12 @@ static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 /* head_out: [grid*grid][8] logits (score, ox, oy, w, h, -, -, -); hann: [grid*grid];
  * geo: search-crop geometry {x0m, y0m, scale, side}; out: {score, X1, Y1, W, H, idx} floats
- * (clipped float box in frame pixels), ibox: rounded integer box */
+ * (clipped float box in frame pixels), ibox: rounded integer box.
+ *
+ * The argmax cell only selects a 3x3 window; the box is the response^2-weighted mean of the
+ * window cells' own predictions (each cell predicts the centre with an offset range of
+ * [-1, 2] cells, so every cell of the window can point at the same centre). A near-tie between
+ * two neighbouring cells therefore moves the box by a second-order amount only. */
 void vto_decode(const float* head_out, const float* hann, int grid, const float* geo, int frame_w,
                 int frame_h, float* out, int32_t* ibox) {
     int n = grid * grid, best = 0;
@@ -262,14 +267,28 @@ void vto_decode(const float* head_out, const float* hann, int grid, const float*
         float r = s * hann[i];
         if (r > best_resp) { best_resp = r; best = i; }
     }
-    const float* o = head_out + best * 8;
-    float score = sigmoidf_(o[0]);
-    float offx = sigmoidf_(o[1]), offy = sigmoidf_(o[2]);
-    float wn = sigmoidf_(o[3]), hn = sigmoidf_(o[4]);
-    int ix = best % grid, iy = best / grid;
+    float score = sigmoidf_(head_out[best * 8 + 0]);
+    int bx = best % grid, by = best / grid;
+    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            int ix = bx + dx, iy = by + dy;
+            if (ix < 0 || iy < 0 || ix >= grid || iy >= grid) continue;
+            const float* o = head_out + (iy * grid + ix) * 8;
+            float r = sigmoidf_(o[0]) * hann[iy * grid + ix];
+            float w = r * r;
+            float offx = 3.0f * sigmoidf_(o[1]) - 1.0f;
+            float offy = 3.0f * sigmoidf_(o[2]) - 1.0f;
+            float cxj = ((float)ix + offx) / (float)grid;
+            float cyj = ((float)iy + offy) / (float)grid;
+            sw = sw + w;
+            scx = scx + w * cxj;
+            scy = scy + w * cyj;
+            sbw = sbw + w * sigmoidf_(o[3]);
+            sbh = sbh + w * sigmoidf_(o[4]);
+        }
+    float cxn = scx / sw, cyn = scy / sw, wn = sbw / sw, hn = sbh / sw;
     float side = geo[3];
-    float cxn = ((float)ix + offx) / (float)grid;
-    float cyn = ((float)iy + offy) / (float)grid;
     /* crop origin in frame pixels = x0m + 0.5 */
     float cx = (geo[0] + 0.5f) + cxn * side;
     float cy = (geo[1] + 0.5f) + cyn * side;

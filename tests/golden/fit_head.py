@@ -1,0 +1,209 @@
+"""Fits the centre head of a synthetic model and writes it to
+gstreamer-vit-tracker_amd/assets/head_<config>.npz  (the committed, trained part of the weights).
+
+Why this exists: the reference's network (object_tracking_vittrack_2023sep.rknn,
+/root/reference/src/main.rs:25) is not available, so the encoder weights are a seeded hash
+(gstreamer-vit-tracker_amd/weights.py). A random head on top of them produces a flat score map,
+and a closed-loop HIP-vs-oracle parity test on such a map would hinge on argmax ties. This script
+trains only the small convolutional head, on synthetic moving-square crops, against features that
+the CPU oracle's encoder computes from exactly those seeded weights.
+
+Run (CPU only, minutes):  python tests/golden/fit_head.py tiny cfg2 cfg3 [cfg5]
+Deterministic up to BLAS summation order (seeds fixed).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import gstreamer_vit_tracker_amd as vt  # noqa: E402
+from oracle import vit_ref as R  # noqa: E402
+
+
+def make_samples(model: R.Model, n: int, seed: int, w=960, h=540):
+    """-> feats [n, Ns, D] (bf16-valued f32), targets [n, 4] = (cxn, cyn, wn, hn) in crop units"""
+    rng = np.random.default_rng(seed)
+    feats, targets = [], []
+    hdr = model.hdr
+    for i in range(n):
+        sw = int(rng.integers(36, 120))
+        sh = sw if rng.random() < 0.6 else int(rng.integers(36, 120))
+        sc = vt.synth.MovingSquare(w, h, square=max(sw, sh), seed=int(rng.integers(1 << 30)))
+        # rectangle: crop the square texture
+        x = int(rng.integers(0, w - sw))
+        y = int(rng.integers(0, h - sh))
+        yy = sc.bg_y.copy()
+        yy[y:y + sh, x:x + sw] = sc.sq_y[:sh, :sw]
+        uv = np.full(((h + 1) // 2, w // 2, 2), 128, np.uint8)
+        uv[y // 2:(y + sh + 1) // 2, x // 2:(x + sw + 1) // 2, 0] = sc.sq_u
+        uv[y // 2:(y + sh + 1) // 2, x // 2:(x + sw + 1) // 2, 1] = sc.sq_v
+        buf = np.concatenate([yy.reshape(-1), uv.reshape(-1)])
+        fr = R.Frame.nv12(buf, w, h)
+        gt = np.array([x, y, sw, sh], np.float32)
+        # template from the true box; search window from a jittered "previous" box
+        tpl = R.preproc(fr, gt, 2.0, model.T, model.patch, model.kpad, hdr["norm_a"],
+                        hdr["norm_b"])
+        jit = rng.uniform(-0.22, 0.22, 2) * 4.0 * np.sqrt(sw * sh) * (rng.random() < 0.85)
+        sj = np.exp(rng.uniform(-0.12, 0.12, 2))
+        pw, ph = sw * sj[0], sh * sj[1]
+        prev = np.array([x + sw / 2 + jit[0] - pw / 2, y + sh / 2 + jit[1] - ph / 2, pw, ph],
+                        np.float32)
+        geo = R.crop_geometry(prev, 4.0, model.S)
+        srch = R.preproc(fr, prev, 4.0, model.S, model.patch, model.kpad, hdr["norm_a"],
+                         hdr["norm_b"])
+        out = model.forward(np.concatenate([tpl, srch], axis=0))
+        feats.append(out["feat"])
+        side = geo[3]
+        targets.append([(x + sw / 2 - (geo[0] + 0.5)) / side, (y + sh / 2 - (geo[1] + 0.5)) / side,
+                        sw / side, sh / side])
+    return np.stack(feats).astype(np.float32), np.array(targets, np.float32)
+
+
+class Head(torch.nn.Module):
+    def __init__(self, d, c):
+        super().__init__()
+        self.c0 = torch.nn.Conv2d(d, c, 1)
+        self.c1 = torch.nn.Conv2d(c, c, 3, padding=1)
+        self.c2 = torch.nn.Conv2d(c, c, 3, padding=1)
+        self.c3 = torch.nn.Conv2d(c, c, 3, padding=1)
+        self.c4 = torch.nn.Conv2d(c, 5, 1)
+
+    def forward(self, x):
+        x = F.relu(self.c0(x))
+        x = F.relu(self.c1(x))
+        x = F.relu(self.c2(x))
+        x = F.relu(self.c3(x))
+        return self.c4(x)
+
+
+def fit(cfg_name: str, n_train: int, steps: int):
+    cfg = vt.weights.get_config(cfg_name)
+    torch.manual_seed(0)
+    t0 = time.time()
+    blob = vt.weights.pack_blob(cfg, vt.weights.generate_tensors(cfg, use_asset=False))
+    model = R.Model(blob)
+    cache = os.path.join(os.environ.get("VT_FIT_CACHE", "/tmp/vt_fit_cache"),
+                         f"{cfg.name}_{n_train}.npz")
+    if os.path.exists(cache):
+        with np.load(cache) as z:
+            feats, tg = z["feats"], z["tg"]
+    else:
+        feats, tg = make_samples(model, n_train, seed=1234)
+        os.makedirs(os.path.dirname(cache), exist_ok=True)
+        np.savez(cache, feats=feats, tg=tg)
+    g, d, c = model.gs, model.D, model.C
+    print(f"[{cfg.name}] features {feats.shape} in {time.time() - t0:.1f}s", flush=True)
+    x = torch.from_numpy(feats).reshape(n_train, g, g, d).permute(0, 3, 1, 2).contiguous()
+    tgt = torch.from_numpy(tg)
+    # labels
+    cx, cy = tgt[:, 0] * g, tgt[:, 1] * g
+    ix = cx.floor().clamp(0, g - 1).long()
+    iy = cy.floor().clamp(0, g - 1).long()
+    gx = torch.arange(g).float() + 0.5
+    heat = torch.exp(-((gx[None, None, :] - cx[:, None, None]) ** 2 +
+                       (gx[None, :, None] - cy[:, None, None]) ** 2) / (2 * 0.65 ** 2))
+    inside = ((tgt[:, 0] > 0) & (tgt[:, 0] < 1) & (tgt[:, 1] > 0) & (tgt[:, 1] < 1)).float()
+    head = Head(d, c)
+    opt = torch.optim.Adam(head.parameters(), lr=2e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-3, total_steps=steps)
+    ar = torch.arange(n_train)
+    for step in range(steps):
+        out = head(x)
+        score_loss = F.binary_cross_entropy_with_logits(out[:, 0], heat * inside[:, None, None])
+        # every cell of the 3x3 window around the positive cell regresses the SAME centre (offset
+        # range [-1, 2] cells: 3*sigmoid - 1) and the same size, so the decode's window mean is
+        # insensitive to which of two near-tied cells wins the argmax
+        loss_reg = 0.0
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                jy, jx = (iy + dy).clamp(0, g - 1), (ix + dx).clamp(0, g - 1)
+                q = out[ar, :, jy, jx]
+                tx = (cx - jx.float()).clamp(-0.97, 1.97)
+                ty = (cy - jy.float()).clamp(-0.97, 1.97)
+                wgt = inside * (1.0 if (dx == 0 and dy == 0) else 0.5)
+                loss_reg = loss_reg + (
+                    F.l1_loss(3 * torch.sigmoid(q[:, 1]) - 1, tx, reduction="none") * wgt).mean() + (
+                    F.l1_loss(3 * torch.sigmoid(q[:, 2]) - 1, ty, reduction="none") * wgt).mean() + (
+                    F.l1_loss(torch.sigmoid(q[:, 3]), tgt[:, 2], reduction="none") * wgt).mean() + (
+                    F.l1_loss(torch.sigmoid(q[:, 4]), tgt[:, 3], reduction="none") * wgt).mean()
+        loss = 20.0 * score_loss + loss_reg
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if step % 50 == 0 or step == steps - 1:
+            print(f"[{cfg.name}] step {step} loss {loss.item():.4f} score {score_loss.item():.4f} "
+                  f"reg {float(loss_reg.detach()):.4f} ({time.time() - t0:.0f}s)", flush=True)
+
+    def conv3(wt):  # [Cout, Cin, 3, 3] -> [Cout, (ky*3+kx)*Cin + ci]
+        return wt.detach().permute(0, 2, 3, 1).reshape(wt.shape[0], -1).numpy()
+
+    w4 = np.zeros((8, c), np.float32)
+    b4 = np.zeros((1, 8), np.float32)
+    w4[:5] = head.c4.weight.detach().reshape(5, c).numpy()
+    b4[0, :5] = head.c4.bias.detach().numpy()
+    b4[0, 5:] = 0.0
+    asset = {
+        "head.w0": head.c0.weight.detach().reshape(c, d).numpy(),
+        "head.b0": head.c0.bias.detach().numpy().reshape(1, c),
+        "head.w1": conv3(head.c1.weight), "head.b1": head.c1.bias.detach().numpy().reshape(1, c),
+        "head.w2": conv3(head.c2.weight), "head.b2": head.c2.bias.detach().numpy().reshape(1, c),
+        "head.w3": conv3(head.c3.weight), "head.b3": head.c3.bias.detach().numpy().reshape(1, c),
+        "head.w4": w4, "head.b4": b4,
+    }
+    # the bf16 tensors are stored as the bf16-rounded values so the asset is what the blob holds
+    for k in vt.weights.HEAD_BF16:
+        asset[k] = R.bf16r(asset[k].astype(np.float32))
+    path = vt.weights.head_asset_path(cfg)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **{k: v.astype(np.float32) for k, v in asset.items()})
+    print(f"[{cfg.name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
+    validate(cfg_name)
+
+
+def validate(cfg_name: str, frames: int = 40):
+    """closed loop on a held-out clip with the oracle: IoU vs ground truth and score margin"""
+    cfg = vt.weights.get_config(cfg_name)
+    wpath = vt.weights.ensure_weights(cfg_name, force=True)
+    trk = R.VitTrackRef(wpath)
+    big = cfg.search >= 256
+    w, h = (1920, 1080) if big else (640, 480)
+    sc = vt.synth.MovingSquare(w, h, 64, seed=0)
+    ious, scores, margins = [], [], []
+    for t in range(frames):
+        fr = R.Frame.nv12(sc.frame_nv12(t), w, h)
+        if t == 0:
+            trk.init(fr, sc.gt_box(0))
+        r = trk.update(fr, taps=True)
+        gx, gy, gw, gh = sc.gt_box(t)
+        bx, by, bw, bh = r.bbox
+        iw = max(0, min(gx + gw, bx + bw) - max(gx, bx))
+        ih = max(0, min(gy + gh, by + bh) - max(gy, by))
+        ious.append(iw * ih / (gw * gh + bw * bh - iw * ih))
+        scores.append(r.score)
+        s = 1 / (1 + np.exp(-trk.last["head_out"][:, 0])) * trk.m.t["hann"].reshape(-1)
+        top = np.sort(s)[-2:]
+        margins.append(float(top[1] - top[0]))
+    print(f"[{cfg.name}] validate: IoU vs GT min {min(ious):.3f} mean {np.mean(ious):.3f}; score "
+          f"min {min(scores):.3f}; top1-top2 response margin min {min(margins):.3f} "
+          f"median {np.median(margins):.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("FIT_THREADS", "8")))
+    names = sys.argv[1:] or ["tiny"]
+    for nme in names:
+        if nme.startswith("validate:"):
+            validate(nme.split(":", 1)[1])
+            continue
+        cfgs = {"tiny": (256, 500), "cfg2": (160, 400), "cfg3": (128, 400), "cfg5": (64, 300)}
+        n, st = cfgs.get(nme, (128, 400))
+        fit(nme, n, st)

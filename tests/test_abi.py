@@ -1,0 +1,54 @@
+"""The C-ABI libraries load and export every symbol their headers declare (no GPU needed; no
+compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vth?_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol(vt):
+    names = _declared("vittrack_hip.h")
+    assert len(names) >= 30
+    assert os.path.exists(vt.LIB_PATH), "run python __graft_entry__.py first"
+    L = ctypes.CDLL(vt.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(vt.EXPORTS) == names
+    assert L.vt_abi_version() == 1
+
+
+def test_host_library_exports_every_declared_symbol(vt):
+    from gstreamer_vit_tracker_amd import hostlib
+    names = _declared("vittrack_host.h")
+    L = hostlib.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(hostlib.EXPORTS) == names
+
+
+def test_struct_layouts_match_header(vt):
+    assert ctypes.sizeof(vt.CBBox) == 16
+    assert ctypes.sizeof(vt.CResult) == 24       # 24 B of result per frame
+    assert ctypes.sizeof(vt.CFrame) == 40
+    assert ctypes.sizeof(vt.CConfig) == 24 + 32
+    assert ctypes.sizeof(vt.CKernelTime) == 48 + 8 + 16
+
+
+def test_no_gpu_means_loud_failure_not_fallback(vt, weights_tiny):
+    """Without a gfx950 device creation must fail with VT_ERR_NO_DEVICE; it must never silently
+    compute on the CPU."""
+    if vt.device_count() > 0:
+        return  # on a GPU box the gpu-marked tests cover creation
+    import pytest
+    with pytest.raises(vt.VtError) as e:
+        vt.VitTrack.new(weights_tiny)
+    assert e.value.code == -2
+    with pytest.raises(vt.VtError):
+        vt.nv12_full_to_rgb(__import__("numpy").zeros(96, "uint8"), 8, 8)

