@@ -76,7 +76,7 @@ EXPORTS = [
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
     "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
-    "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_qkv_bf16", "vt_op_attention_bf16",
+    "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_layernorm",
 ]
 
@@ -141,6 +141,7 @@ def lib():
                                          c_void_p]
     u16p, fp = POINTER(c_uint16), POINTER(c_float)
     L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int]
+    L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int]
     L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
@@ -432,6 +433,12 @@ def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0):
     _check(lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
                                  _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue))
     return c
+
+
+def op_gemm_bench(M, N, K, epilogue, cfg=-1, iters=50, device=0) -> float:
+    us = c_float()
+    _check(lib().vt_op_gemm_bench(device, M, N, K, epilogue, cfg, iters, byref(us)))
+    return float(us.value)
 
 
 def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0):

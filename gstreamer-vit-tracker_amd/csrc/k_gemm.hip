@@ -8,8 +8,11 @@
 // Structure (CDNA4):
 //   * 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN (128x128 or 64x64), BK = 64.
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
-//     instruction = 8 tile rows of 128 B); two LDS stages; the loads of K-tile t+1 are in flight
-//     while the MFMAs of tile t run; one barrier per K-tile.
+//     instruction = 8 tile rows of 128 B) into a ring of NS LDS stages: the loads of K-tiles
+//     t+1 .. t+NS-2 stay in flight across the barrier while the MFMAs of tile t run (counted
+//     s_waitcnt vmcnt(N), raw s_barrier: a plain __syncthreads() would drain the queue). At
+//     M = 720 a block's MFMA work per K-tile (~0.1 us) is far shorter than an L2/HBM round trip,
+//     so the prefetch distance, not the tile shape, sets the time per K-tile.
 //   * LDS image: rows of 128 B (64 bf16); the 16-B chunk c of row r is stored at chunk
 //     c ^ ((r >> 1) & 7). LDS-DMA writes lane-linear, so the XOR is applied to the per-lane
 //     SOURCE address and again on the read (guide rule 21). With this swizzle the ds_read_b128
@@ -38,7 +41,13 @@ __device__ __forceinline__ int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
-template <int BM, int BN, bool ROW_ON_LANE>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NS, bool ROW_ON_LANE>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                               f32x16_t (&acc)[BM / 64][BN / 64]) {
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
@@ -91,14 +100,22 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         bswz[j] = (row >> 1) & 7;
     }
 
+    constexpr int IPS = BM / 32 + BN / 32;  // LDS-DMA instructions per wave per stage
     const int nk = p.K / GEMM_BK;
-    stage(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // tile kt has landed (this wave's pieces) and every wave is done reading stage cur^1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        // Tile kt must have landed; tiles kt+1 .. kt+NS-2 (those that exist) may stay in flight.
+        const int ahead = min(NS - 2, nk - 1 - kt);
+        if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * IPS>();
+        else if (NS >= 3 && ahead == 1) wait_vmcnt<IPS>();
+        else wait_vmcnt<0>();
+        // every wave's pieces of tile kt are in LDS, and every wave has finished reading the
+        // stage of tile kt-1, which the next prefetch overwrites
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
         const char* sbase = smem + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -122,10 +139,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
                                                                             acc[i][j], 0, 0, 0);
                 }
         }
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int NS, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TM = BM / 64, TN = BN / 64, WM = BM / 2, WN = BN / 2;
@@ -144,28 +162,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        gemm_mainloop<BM, BN, false>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, NS, false>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * WN + j * 32 + l31;
                 const float bias = p.bias ? p.bias[n] : 0.0f;
+                // All 16 reads of the old value / positional row are issued before the first use
+                // (rows clamped so every address is valid): a load inside the `m < M` branch makes
+                // hipcc wait vmcnt(0) per element, 16 serial L2 round trips per tile.
+                float addend[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * WM + i * 32 + acc_row(r, half);
-                    if (m < p.M) {
-                        float* dst = p.Cf + (size_t)m * p.ldc + n;
-                        float v = acc[i][j][r] + bias;
-                        if constexpr (EPI == EPI_F32_POS)
-                            v += p.pos[(size_t)(m % p.pos_rows) * p.ldc + n];
-                        if constexpr (EPI == EPI_RESID) v += *dst;
-                        *dst = v;
-                    }
+                    const int mc = m < p.M ? m : p.M - 1;
+                    if constexpr (EPI == EPI_F32_POS)
+                        addend[r] = p.pos[(size_t)(mc % p.pos_rows) * p.ldc + n];
+                    else if constexpr (EPI == EPI_RESID)
+                        addend[r] = p.Cf[(size_t)mc * p.ldc + n];
+                    else
+                        addend[r] = 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * WM + i * 32 + acc_row(r, half);
+                    if (m < p.M) p.Cf[(size_t)m * p.ldc + n] = (acc[i][j][r] + bias) + addend[r];
                 }
             }
     } else if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
-        gemm_mainloop<BM, BN, true>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, NS, true>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * WM + i * 32 + l31;
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         const int D = p.D;
         if (n0 < 2 * D) {
             // q (scaled by 1/8 = 1/sqrt(64), exact in bf16) and k: row-major [M][2D]
-            gemm_mainloop<BM, BN, true>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, NS, true>(p, smem, m0, n0, acc);
             const float sc = (n0 < D) ? 0.125f : 1.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         } else {
             // v: transposed per head, Vt[b][h][d][t] with t contiguous (npad per row), so the
             // attention kernel reads 4 consecutive keys of one d with one 8-B load
-            gemm_mainloop<BM, BN, false>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, NS, false>(p, smem, m0, n0, acc);
             const int heads = D >> 6;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -241,17 +267,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int EPI>
+// Tile configurations: {BM, BN, NS}. 64x64 with a 4-deep ring (64 KiB, two blocks per CU) for the
+// small-M shapes of one or a few streams; 128x128 with a 3-deep ring (96 KiB) once the grid fills
+// the chip several times over.
+template <int BM, int BN, int NS, int EPI>
 static hipError_t prepare_cfg() {
-    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI>),
+    constexpr int smem = NS * (BM + BN) * ROW_BYTES;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NS, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 template <int EPI>
 static hipError_t prepare_epi() {
-    hipError_t e = prepare_cfg<128, 128, EPI>();
-    return e != hipSuccess ? e : prepare_cfg<64, 64, EPI>();
+    hipError_t e = prepare_cfg<128, 128, 3, EPI>();
+    if (e != hipSuccess) return e;
+    e = prepare_cfg<128, 128, 2, EPI>();
+    if (e != hipSuccess) return e;
+    e = prepare_cfg<64, 64, 2, EPI>();
+    return e != hipSuccess ? e : prepare_cfg<64, 64, 4, EPI>();
 }
 
 // Raise the dynamic-LDS limit of every instantiation once per device, outside any stream capture.
@@ -265,33 +298,65 @@ hipError_t gemm_prepare() {
     return prepare_epi<EPI_F32>();
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int NS, int EPI>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    constexpr int smem = NS * (BM + BN) * ROW_BYTES;
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NS, EPI>), dim3(tiles), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
+// 0: 64x64 ring 4, 1: 128x128 ring 3, 2: 64x64 ring 2, 3: 128x128 ring 2.
+// Chosen from a sweep on MI355X over the tracker's shapes (M = 720 * streams; profiles/
+// gemm_sweep_r01.txt): at these sizes the kernel is bound by global->LDS traffic and occupancy, not
+// by MFMA issue, so the small tile with two or more blocks per CU wins until the grid is several
+// waves deep; the deeper ring only pays for the long-K, small-M fc2.
+int gemm_pick_config(int M, int N, int K, int epilogue) {
+    const long tiles128 = (long)((M + 127) / 128) * (N / 128);
+    const bool n128 = (N % 128) == 0;
+    switch (epilogue) {
+        case EPI_QKV: return (n128 && tiles128 >= 400) ? 3 : 2;
+        case EPI_RESID:
+            if (K >= 2048 && M <= 2048) return 0;
+            if (K >= 2048 && n128 && tiles128 >= 256) return 3;
+            return 2;
+        default: return 2;
+    }
+}
+
+const char* gemm_config_name(int cfg) {
+    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
+    return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
+}
+
 template <int EPI>
-static hipError_t launch_epi(const GemmArgs& a, hipStream_t st) {
-    // 128x128 tiles when they alone fill the 256 CUs (or N forces it), else 64x64 for more blocks
-    const long big = (long)((a.M + 127) / 128) * (a.N / 128);
-    if ((a.N % 128 == 0) && big >= 192) return launch_cfg<128, 128, EPI>(a, st);
-    return launch_cfg<64, 64, EPI>(a, st);
+static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_cfg<64, 64, 4, EPI>(a, st);
+        case 1: return launch_cfg<128, 128, 3, EPI>(a, st);
+        case 2: return launch_cfg<64, 64, 2, EPI>(a, st);
+        case 3: return launch_cfg<128, 128, 2, EPI>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st) {
+    if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
+    if ((cfg == 1 || cfg == 3) && a.N % 128 != 0) return hipErrorInvalidValue;
+    if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0 ||
+                                ((cfg == 1 || cfg == 3) && a.D % 128 != 0)))
+        return hipErrorInvalidValue;
+    switch (epilogue) {
+        case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
+        case EPI_RESID: return launch_epi<EPI_RESID>(a, cfg, st);
+        case EPI_GELU_BF16: return launch_epi<EPI_GELU_BF16>(a, cfg, st);
+        case EPI_RELU_BF16: return launch_epi<EPI_RELU_BF16>(a, cfg, st);
+        case EPI_QKV: return launch_epi<EPI_QKV>(a, cfg, st);
+        case EPI_F32: return launch_epi<EPI_F32>(a, cfg, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {
-    if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
-    if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
-        return hipErrorInvalidValue;
-    switch (epilogue) {
-        case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, st);
-        case EPI_RESID: return launch_epi<EPI_RESID>(a, st);
-        case EPI_GELU_BF16: return launch_epi<EPI_GELU_BF16>(a, st);
-        case EPI_RELU_BF16: return launch_epi<EPI_RELU_BF16>(a, st);
-        case EPI_QKV: return launch_epi<EPI_QKV>(a, st);
-        case EPI_F32: return launch_epi<EPI_F32>(a, st);
-        default: return hipErrorInvalidValue;
-    }
+    return launch_gemm_cfg(a, epilogue, gemm_pick_config(a.M, a.N, a.K, epilogue), st);
 }

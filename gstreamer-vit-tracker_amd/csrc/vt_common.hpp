@@ -64,6 +64,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);
+hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st);
+int gemm_pick_config(int M, int N, int K, int epilogue);
+const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
 
 // y[r] (bf16) = LN(x[in_row(r)]) ; in_row(r) = (r / group) * in_stride + in_off + r % group

@@ -78,12 +78,10 @@ struct Profiler {
 
 const char* g_last_gemm_name = "";  // set by launch_gemm_named below
 
-static const char* gemm_name(int epi, int M, int N) {
+static const char* gemm_name(int epi, int M, int N, int K) {
     static const char* tags[] = {"f32pos", "resid", "gelu", "relu", "qkv", "f32"};
-    const long big = (long)((M + 127) / 128) * (N / 128);
-    const bool b128 = (N % 128 == 0) && big >= 192;
     static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s", tags[epi], b128 ? "128x128" : "64x64");
+    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s", tags[epi], gemm_config_name(gemm_pick_config(M, N, K, epi)));
     return buf;
 }
 
@@ -338,7 +336,7 @@ int Engine::run_pass(Profiler* prof) {
         const double fl = 2.0 * a.M * a.N * a.K;
         const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                           (epi == EPI_RESID || epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
-        L(gemm_name(epi, a.M, a.N), fl, by, [&] { return launch_gemm(a, epi, stream); });
+        L(gemm_name(epi, a.M, a.N, a.K), fl, by, [&] { return launch_gemm(a, epi, stream); });
     };
     auto tap = [&](int slot) {
         if (taps && lerr == hipSuccess)
@@ -1032,6 +1030,49 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
             memcpy(c_inout + i, &u, 4);
         }
     }
+    return VT_OK;
+}
+
+// Timing helper for kernel tuning: runs the GEMM kernel `iters` times on device-resident random
+// operands with tile configuration `cfg` (<0: the launcher's own choice) and returns the mean time
+// per launch in microseconds (HIP events on the null stream).
+int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters, float* us_out) {
+    if (M <= 0 || N % 64 || K % 64 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(gemm_prepare());
+    const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 31) / 32 * 32;
+    DevBuf da, dw, db, dc, dcb, dvt;
+    HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
+    HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
+    HIPCHK(dvt.alloc((size_t)(N / 64 + 1) * 64 * npad * 2));
+    std::vector<bf16_t> ha((size_t)M * K), hw((size_t)N * K);
+    uint32_t seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (bf16_t)(0x3c00u + ((seed >> 9) & 0x3ffu) + ((seed >> 3) & 0x8000u)); };
+    for (auto& v : ha) v = rnd();
+    for (auto& v : hw) v = rnd();
+    HIPCHK(hipMemcpy(da.p, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(db.p, 0, (size_t)N * 4));
+    HIPCHK(hipMemset(dc.p, 0, (size_t)M * N * 4));
+    GemmArgs g{};
+    g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
+    g.M = M; g.N = N; g.K = K; g.Cf = (float*)dc.p; g.ldc = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    g.pos = (const float*)dc.p; g.pos_rows = M;
+    g.qk = (bf16_t*)dcb.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
+    if (epilogue == EPI_QKV && (N % 192 || tokens != M)) return set_err(VT_ERR_INVALID_ARG, "qkv bench: N = 3D, D % 64 == 0, M % 4 == 0");
+    if (cfg < 0) cfg = gemm_pick_config(M, N, K, epilogue);
+    for (int i = 0; i < 3; ++i) HIPCHK(launch_gemm_cfg(g, epilogue, cfg, nullptr));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIPCHK(launch_gemm_cfg(g, epilogue, cfg, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_out = ms * 1000.0f / iters;
     return VT_OK;
 }
 

@@ -212,6 +212,12 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
  * 3 = ReLU -> bf16 (widened). Host pointers. K % 64 == 0, N % 64 == 0. */
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
                     float* c_inout, int M, int N, int K, int epilogue);
+/* Kernel-tuning helper: mean microseconds per launch of the GEMM kernel on device-resident random
+ * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
+ * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2,
+ * <0 = the launcher's own choice. */
+int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
+                     float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
  * npad = tokens rounded up to 32, padding zero); bf16 results widened to f32. */

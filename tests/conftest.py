@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu")
+    # rebuild stale native libraries (no-op when up to date; hipcc cross-compiles without a GPU)
+    import __graft_entry__
+    __graft_entry__.build()
 
 
 def _has_gpu():

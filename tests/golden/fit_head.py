@@ -67,21 +67,31 @@ def make_samples(model: R.Model, n: int, seed: int, w=960, h=540):
     return np.stack(feats).astype(np.float32), np.array(targets, np.float32)
 
 
+def unfold3x3(t):
+    """t [n, g, g, c] -> [n, g, g, 9c], column (ky*3+kx)*c + ci, zero padding — the same im2col the
+    HIP head uses, so the 3x3 convolutions run as plain matrix products (fast on CPU BLAS)"""
+    n, g, _, c = t.shape
+    p = F.pad(t, (0, 0, 1, 1, 1, 1))
+    return torch.cat([p[:, ky:ky + g, kx:kx + g, :] for ky in range(3) for kx in range(3)], dim=-1)
+
+
 class Head(torch.nn.Module):
+    """channels-last centre head: 1x1 conv, three 3x3 convs (as im2col + linear), 1x1 conv to 5"""
+
     def __init__(self, d, c):
         super().__init__()
-        self.c0 = torch.nn.Conv2d(d, c, 1)
-        self.c1 = torch.nn.Conv2d(c, c, 3, padding=1)
-        self.c2 = torch.nn.Conv2d(c, c, 3, padding=1)
-        self.c3 = torch.nn.Conv2d(c, c, 3, padding=1)
-        self.c4 = torch.nn.Conv2d(c, 5, 1)
+        self.c0 = torch.nn.Linear(d, c)
+        self.c1 = torch.nn.Linear(9 * c, c)
+        self.c2 = torch.nn.Linear(9 * c, c)
+        self.c3 = torch.nn.Linear(9 * c, c)
+        self.c4 = torch.nn.Linear(c, 5)
 
-    def forward(self, x):
+    def forward(self, x):                     # x [n, g, g, d]
         x = F.relu(self.c0(x))
-        x = F.relu(self.c1(x))
-        x = F.relu(self.c2(x))
-        x = F.relu(self.c3(x))
-        return self.c4(x)
+        x = F.relu(self.c1(unfold3x3(x)))
+        x = F.relu(self.c2(unfold3x3(x)))
+        x = F.relu(self.c3(unfold3x3(x)))
+        return self.c4(x).permute(0, 3, 1, 2)  # [n, 5, g, g]
 
 
 def fit(cfg_name: str, n_train: int, steps: int):
@@ -101,7 +111,7 @@ def fit(cfg_name: str, n_train: int, steps: int):
         np.savez(cache, feats=feats, tg=tg)
     g, d, c = model.gs, model.D, model.C
     print(f"[{cfg.name}] features {feats.shape} in {time.time() - t0:.1f}s", flush=True)
-    x = torch.from_numpy(feats).reshape(n_train, g, g, d).permute(0, 3, 1, 2).contiguous()
+    x = torch.from_numpy(feats).reshape(n_train, g, g, d).contiguous()
     tgt = torch.from_numpy(tg)
     # labels
     cx, cy = tgt[:, 0] * g, tgt[:, 1] * g
@@ -143,22 +153,14 @@ def fit(cfg_name: str, n_train: int, steps: int):
             print(f"[{cfg.name}] step {step} loss {loss.item():.4f} score {score_loss.item():.4f} "
                   f"reg {float(loss_reg.detach()):.4f} ({time.time() - t0:.0f}s)", flush=True)
 
-    def conv3(wt):  # [Cout, Cin, 3, 3] -> [Cout, (ky*3+kx)*Cin + ci]
-        return wt.detach().permute(0, 2, 3, 1).reshape(wt.shape[0], -1).numpy()
-
     w4 = np.zeros((8, c), np.float32)
     b4 = np.zeros((1, 8), np.float32)
-    w4[:5] = head.c4.weight.detach().reshape(5, c).numpy()
+    w4[:5] = head.c4.weight.detach().numpy()
     b4[0, :5] = head.c4.bias.detach().numpy()
-    b4[0, 5:] = 0.0
-    asset = {
-        "head.w0": head.c0.weight.detach().reshape(c, d).numpy(),
-        "head.b0": head.c0.bias.detach().numpy().reshape(1, c),
-        "head.w1": conv3(head.c1.weight), "head.b1": head.c1.bias.detach().numpy().reshape(1, c),
-        "head.w2": conv3(head.c2.weight), "head.b2": head.c2.bias.detach().numpy().reshape(1, c),
-        "head.w3": conv3(head.c3.weight), "head.b3": head.c3.bias.detach().numpy().reshape(1, c),
-        "head.w4": w4, "head.b4": b4,
-    }
+    asset = {"head.w4": w4, "head.b4": b4}
+    for k, lin in enumerate((head.c0, head.c1, head.c2, head.c3)):
+        asset[f"head.w{k}"] = lin.weight.detach().numpy().copy()
+        asset[f"head.b{k}"] = lin.bias.detach().numpy().reshape(1, c).copy()
     # the bf16 tensors are stored as the bf16-rounded values so the asset is what the blob holds
     for k in vt.weights.HEAD_BF16:
         asset[k] = R.bf16r(asset[k].astype(np.float32))
