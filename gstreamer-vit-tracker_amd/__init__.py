@@ -445,7 +445,7 @@ def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0):
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
     w_bits = np.ascontiguousarray(w_bits, np.uint16)
     bias = np.ascontiguousarray(bias, np.float32)
-    npad = (tokens + 31) // 32 * 32
+    npad = (tokens + 63) // 64 * 64
     qk = np.empty((B * tokens, 2 * D), np.float32)
     vt = np.empty((B * (D // 64), 64, npad), np.float32)
     _check(lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),

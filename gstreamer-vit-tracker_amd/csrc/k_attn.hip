@@ -1,8 +1,7 @@
 // k_attn.hip — joint template+search attention for gfx950 (head dim 64, N <= ~1k tokens).
 //
-// One wave owns 32 query rows of one (stream, head) and walks the keys in tiles of 32 with an
-// online softmax. Orientation is chosen so that nothing crosses lanes except one half-swap per
-// reduction:
+// One wave owns 32 query rows of one (stream, head) and walks key tiles of 32 with an online
+// softmax. Orientation is chosen so that nothing crosses lanes except one half-swap per reduction:
 //   S^T[key][q] = K_tile · Q^T        (MFMA A = K rows, B = Q rows)  -> the query is on the lane,
 //                                      its 32 scores are in 16 registers x 2 lane halves
 //   O^T[d][q]  += Vt_tile · P^T       (MFMA A = Vt rows, B = the S^T accumulator itself, converted
@@ -14,8 +13,19 @@
 // transposed (Vt[b][h][d][key], written by the QKV GEMM epilogue) is two 8-B loads.
 //
 // Q and K are read straight from the row-major qk[M][2D] buffer (16 B per lane per k-step); Q is
-// already scaled by 1/8. Keys >= tokens (padding of the last tile) are masked to -inf; Vt padding
-// is zero.
+// already scaled by 1/8. The fragments of the next key tile are loaded before the current tile is
+// computed (register double buffer), so L2 latency overlaps the MFMAs and the softmax.
+//
+// Two work splits (same arithmetic per tile):
+//   KVSPLIT = false: the 4 waves of a block take 4 different query blocks (many streams: enough
+//                    blocks to fill the chip, no merge).
+//   KVSPLIT = true : the 4 waves of a block share ONE query block and take every 4th key tile;
+//                    the partial (max, sum, O) are merged through LDS. With one stream there are
+//                    only 12 x 23 query blocks for 256 CUs; splitting the keys gives 4x the waves
+//                    and a 4x shorter dependent chain per wave.
+// Keys >= tokens (padding of the last tile) are masked to -inf; Vt padding is zero.
+#include <cstdlib>
+
 #include "vt_common.hpp"
 
 __device__ __forceinline__ bf16x8_t ld16(const bf16_t* p) {
@@ -24,24 +34,45 @@ __device__ __forceinline__ bf16x8_t ld16(const bf16_t* p) {
 __device__ __forceinline__ bf16x4_t ld8(const bf16_t* p) {
     return *reinterpret_cast<const bf16x4_t*>(p);
 }
-__device__ __forceinline__ float xhalf_max(float v) {
-    return fmaxf(v, __shfl_xor(v, 32));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-    return v + __shfl_xor(v, 32);
+__device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+struct KvFrag {
+    bf16x8_t k[4];      // K rows of the tile, 4 k-steps over d
+    bf16x8_t v[2][2];   // Vt rows [d chunk][key half], keys in the accumulator-operand order
+};
+
+__device__ __forceinline__ void load_tile(KvFrag& f, const bf16_t* kbase, const bf16_t* vbase,
+                                          int kt, int tokens, int ld, int npad, int l31) {
+    const int key = kt * 32 + l31;
+    const int kc = key < tokens ? key : tokens - 1;
+    const bf16_t* krow = kbase + (size_t)kc * ld;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.k[ks] = ld16(krow + ks * 16);
+#pragma unroll
+    for (int dc = 0; dc < 2; ++dc)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16_t* vp = vbase + (size_t)dc * 32 * npad + kt * 32 + 16 * s2;
+            const bf16x4_t lo = ld8(vp), hi = ld8(vp + 8);
+            f.v[dc][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 }
 
+template <bool KVSPLIT>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qk,
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out, int tokens,
                                                         int H, int npad) {
+    __shared__ float s_o[KVSPLIT ? 4 * 32 * 64 : 1];
+    __shared__ float s_ml[KVSPLIT ? 4 * 2 * 64 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int qb = blockIdx.x * 4 + wave;
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = H * 64, ld = 2 * D;
     const int nqb = (tokens + 31) >> 5;
-    if (qb >= nqb) return;  // whole wave exits; no barriers in this kernel
+    const int qb = KVSPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (!KVSPLIT && qb >= nqb) return;  // whole wave exits; no barrier on this path
 
     const int q = qb * 32 + l31;
     const int qc = q < tokens ? q : tokens - 1;
@@ -60,39 +91,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     float m_run = -1.0e30f, l_run = 0.0f;
 
     const int nkt = (tokens + 31) >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int key = kt * 32 + l31;
-        const int kc = key < tokens ? key : tokens - 1;
-        const bf16_t* krow = kbase + (size_t)kc * ld;
-        bf16x8_t kf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks] = ld16(krow + ks * 16);
-        // V fragments for this key tile: [dc][s2] = 8 keys in the permuted order
-        bf16x8_t vf[2][2];
-#pragma unroll
-        for (int dc = 0; dc < 2; ++dc)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16_t* vp = vbase + (size_t)dc * 32 * npad + kt * 32 + 16 * s2;
-                bf16x4_t lo = ld8(vp), hi = ld8(vp + 8);
-                vf[dc][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+    const int kt0 = KVSPLIT ? wave : 0, kstep = KVSPLIT ? 4 : 1;
+    KvFrag cur, nxt;
+    if (kt0 < nkt) load_tile(cur, kbase, vbase, kt0, tokens, ld, npad, l31);
+    for (int kt = kt0; kt < nkt; kt += kstep) {
+        // prefetch the next tile of this wave (clamped: the last iteration reloads a valid tile)
+        const int ktn = (kt + kstep < nkt) ? kt + kstep : kt;
+        load_tile(nxt, kbase, vbase, ktn, tokens, ld, npad, l31);
 
         f32x16_t s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.k[ks], qf[ks], s, 0, 0, 0);
 
         // s[r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*half, query = this lane's
         float mx = -1.0e30f;
+        if (kt * 32 + 32 > tokens) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kidx = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (kidx >= tokens) s[r] = -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int kidx = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (kidx >= tokens) s[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = xhalf_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
@@ -120,17 +144,223 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s2], pf[s2], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s2], pf[s2], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.v[0][s2], pf[s2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.v[1][s2], pf[s2], o1, 0, 0, 0);
         }
+        cur = nxt;
     }
 
-    if (q < tokens) {
+    bf16_t* orow = out + ((size_t)b * tokens + q) * D + h * 64;
+    if constexpr (!KVSPLIT) {
+        if (q < tokens) {
+            const float inv = 1.0f / l_run;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // registers 4g..4g+3 hold d = 8g + 4*half + (0..3)
+                const int d = 8 * g + 4 * half;
+                uint2 a = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                     pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+                uint2 c = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                     pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(orow + d) = a;
+                *reinterpret_cast<uint2*>(orow + 32 + d) = c;
+            }
+        }
+    } else {
+        // merge the 4 key-split partials: O = sum_w O_w e^{m_w - m} / sum_w l_w e^{m_w - m}
+        float* so = s_o + wave * (32 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            so[r * 64 + lane] = o0[r];
+            so[(16 + r) * 64 + lane] = o1[r];
+        }
+        s_ml[(wave * 2 + 0) * 64 + lane] = m_run;
+        s_ml[(wave * 2 + 1) * 64 + lane] = l_run;
+        __syncthreads();
+        float mw[4], m = -1.0e30f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = s_ml[(w * 2 + 0) * 64 + lane];
+            m = fmaxf(m, mw[w]);
+        }
+        float l = 0.0f, sc[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sc[w] = __expf(mw[w] - m);
+            l += s_ml[(w * 2 + 1) * 64 + lane] * sc[w];
+        }
+        const float inv = 1.0f / l;
+        // wave w finalises accumulator registers [8w, 8w+8) of the 32 (two 4-register groups)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int r0 = 8 * wave + 4 * gg;          // 0..28, step 4
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc += s_o[w * (32 * 64) + (r0 + e) * 64 + lane] * sc[w];
+                v[e] = acc * inv;
+            }
+            // register index r0 -> chunk (r0 >= 16), group g = (r0 & 15) / 4 -> d = 8g + 4*half
+            const int d = (r0 >= 16 ? 32 : 0) + 8 * ((r0 & 15) >> 2) + 4 * half;
+            if (q < tokens)
+                *reinterpret_cast<uint2*>(orow + d) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
+// ---- many streams: 4 query blocks per workgroup share the K / Vt tiles through LDS ---------------------
+// 64-key tiles, register-staged (loads of tile t+1 are issued before tile t is computed and written
+// to the other LDS buffer afterwards: one barrier per tile). K image: 128-B rows with the GEMM's
+// chunk swizzle (c ^ ((row >> 1) & 7)) -> conflict-free ds_read_b128; Vt image: 64 rows (d) of 64
+// keys padded to 136 B -> the two 8-B reads per fragment hit 64 distinct banks.
+#define ATT_KT 64
+#define ATT_K_BYTES (ATT_KT * 128)
+#define ATT_V_STRIDE 136
+#define ATT_V_BYTES (64 * ATT_V_STRIDE)
+
+__global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __restrict__ qk,
+                                                            const bf16_t* __restrict__ vt,
+                                                            bf16_t* __restrict__ out, int tokens,
+                                                            int H, int npad) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (ATT_K_BYTES + ATT_V_BYTES)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64, ld = 2 * D;
+    const int nqb = (tokens + 31) >> 5;
+    const int qb = blockIdx.x * 4 + wave;
+    const bool active = qb < nqb;          // inactive waves still stage tiles and hit barriers
+
+    const int q = qb * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16_t* qrow = qk + ((size_t)b * tokens + qc) * ld + h * 64 + half * 8;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(qrow + ks * 16);
+
+    // staging: each thread moves two 16-B chunks of the K tile and two of the Vt tile
+    const bf16_t* kg = qk + (size_t)b * tokens * ld + D + h * 64;
+    const bf16_t* vg = vt + (size_t)(b * H + h) * 64 * npad;
+    int krow[2], kch[2], koff[2], voff[2];
+    const bf16_t* vsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + 256 * j;
+        krow[j] = c >> 3;
+        kch[j] = c & 7;
+        koff[j] = krow[j] * 128 + ((kch[j] ^ ((krow[j] >> 1) & 7)) << 4);
+        voff[j] = (c >> 3) * ATT_V_STRIDE + (c & 7) * 16;
+        vsrc[j] = vg + (size_t)(c >> 3) * npad + (c & 7) * 8;
+    }
+    uint4 kreg[2], vreg[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int key = kt * ATT_KT + krow[j];
+            key = key < tokens ? key : tokens - 1;
+            kreg[j] = *reinterpret_cast<const uint4*>(kg + (size_t)key * ld + kch[j] * 8);
+            vreg[j] = *reinterpret_cast<const uint4*>(vsrc[j] + kt * ATT_KT);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sk = smem + buf * (ATT_K_BYTES + ATT_V_BYTES);
+        char* sv = sk + ATT_K_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<uint4*>(sk + koff[j]) = kreg[j];
+            *reinterpret_cast<uint2*>(sv + voff[j]) = make_uint2(vreg[j].x, vreg[j].y);
+            *reinterpret_cast<uint2*>(sv + voff[j] + 8) = make_uint2(vreg[j].z, vreg[j].w);
+        }
+    };
+
+    f32x16_t o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; }
+    float m_run = -1.0e30f, l_run = 0.0f;
+
+    const int nt = (tokens + ATT_KT - 1) / ATT_KT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) gload(kt + 1);
+        const char* sk = smem + (kt & 1) * (ATT_K_BYTES + ATT_V_BYTES);
+        const char* sv = sk + ATT_K_BYTES;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int key0 = kt * ATT_KT + st * 32;
+            if (key0 >= tokens) break;     // block-uniform
+            bf16x8_t kf[4], vf[2][2];
+            const int row = st * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                kf[ks] = *reinterpret_cast<const bf16x8_t*>(
+                    sk + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vp = sv + (dc * 32 + l31) * ATT_V_STRIDE +
+                                     (st * 32 + 16 * s2 + 4 * half) * 2;
+                    const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(vp);
+                    const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(vp + 16);
+                    vf[dc][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            f32x16_t s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            if (key0 + 32 > tokens) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+            }
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = xhalf_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.0f, p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __expf(s[r] - m_new);
+                psum += p[r];
+            }
+            psum = xhalf_sum(psum);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                union { uint32_t u[4]; bf16x8_t v; } cv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cv.u[e] = pack_bf16x2(p[8 * s2 + 2 * e], p[8 * s2 + 2 * e + 1]);
+                pf[s2] = cv.v;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s2], pf[s2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s2], pf[s2], o1, 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nt) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    if (active && q < tokens) {
         const float inv = 1.0f / l_run;
         bf16_t* orow = out + ((size_t)b * tokens + q) * D + h * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // registers 4g..4g+3 hold d = 8g + 4*half + (0..3)
             const int d = 8 * g + 4 * half;
             uint2 a = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
                                  pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
@@ -142,10 +372,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
 }
 
+// mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles (many streams),
+// -1 = choose. npad must be a multiple of 64 for mode 2.
+hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
+                                 int H, int npad, int mode, hipStream_t st) {
+    const int nqb = (tokens + 31) / 32;
+    if (mode < 0) {
+        const long wgs_lds = (long)((nqb + 3) / 4) * H * B;
+        mode = (wgs_lds >= 512 && npad % 64 == 0) ? 2 : 0;
+    }
+    if (mode == 2 && npad % 64 != 0) return hipErrorInvalidValue;
+    if (mode == 0) {
+        hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
+                           tokens, H, npad);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL(attention_kernel<false>, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk,
+                           vt, out, tokens, H, npad);
+    } else {
+        hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                             int H, int npad, hipStream_t st) {
-    const int nqb = (tokens + 31) / 32;
-    dim3 grid((nqb + 3) / 4, H, B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qk, vt, out, tokens, H, npad);
-    return hipGetLastError();
+    static const int forced = [] {
+        const char* e = getenv("VT_ATTN_MODE");
+        return e ? atoi(e) : -1;
+    }();
+    return launch_attention_mode(qk, vt, out, B, tokens, H, npad, forced, st);
 }

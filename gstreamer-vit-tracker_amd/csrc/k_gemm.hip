@@ -32,8 +32,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
         (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
+// far below the bf16 rounding of the result): one v_rcp, one v_exp and a degree-5 polynomial
+// instead of libm's erff (~3x the instructions), which made the fc1 epilogue a visible share of
+// the kernel at large tiles.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = 1.0f - (poly * t) * __expf(-z * z);   // erf(|x|/sqrt2)
+    const float erfv = x < 0.0f ? -e : e;
+    return 0.5f * x * (1.0f + erfv);
 }
 
 // accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile

@@ -36,7 +36,7 @@ struct StreamState {
 struct ModelDims {
     int patch, T, S, D, H, L, mlp, C, kpad;
     int gt, gs, nt, ns, ntok;   // grids and token counts
-    int npad;                   // ntok rounded up to 32 (attention key padding)
+    int npad;                   // ntok rounded up to 64 (attention key padding)
     float norm_a[3], norm_b[3];
     float success_threshold, ln_eps;
 };
@@ -77,6 +77,9 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 // out[M][D] bf16 = softmax(q k^T) v, q/k rows in qk[M][2D], v transposed in vt[B*H][64][npad]
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                             int H, int npad, hipStream_t st);
+
+hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
+                                 int H, int npad, int mode, hipStream_t st);
 
 // crop + bilinear + normalise -> patch rows; one launch covers streams [b0, b0+nb)
 hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,

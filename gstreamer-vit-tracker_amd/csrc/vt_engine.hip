@@ -179,7 +179,7 @@ int Engine::index_blob(const uint8_t* hc, size_t bytes) {
         return set_err(VT_ERR_FORMAT, "weight blob: template/search not multiples of patch");
     d.gt = d.T / d.patch; d.gs = d.S / d.patch;
     d.nt = d.gt * d.gt; d.ns = d.gs * d.gs; d.ntok = d.nt + d.ns;
-    d.npad = (d.ntok + 31) / 32 * 32;
+    d.npad = (d.ntok + 63) / 64 * 64;
     if (d.D % 128 || d.H != d.D / 64 || d.mlp % 64 || d.C % 64 || d.kpad % 64 ||
         d.kpad < 3 * d.patch * d.patch || (d.ntok & 3) || (d.ns & 3) || d.L <= 0 || d.D > 1536)
         return set_err(VT_ERR_FORMAT, "weight blob: unsupported model shape (D=%d H=%d mlp=%d C=%d "
@@ -1041,7 +1041,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(gemm_prepare());
-    const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 31) / 32 * 32;
+    const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dc, dcb, dvt;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
     HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
@@ -1084,7 +1084,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(gemm_prepare());
-    const int M = B * tokens, H = D / 64, npad = (tokens + 31) / 32 * 32;
+    const int M = B * tokens, H = D / 64, npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dqk, dvt;
     HIPCHK(da.alloc((size_t)M * D * 2)); HIPCHK(dw.alloc((size_t)3 * D * D * 2)); HIPCHK(db.alloc((size_t)3 * D * 4));
     HIPCHK(dqk.alloc((size_t)M * 2 * D * 2)); HIPCHK(dvt.alloc((size_t)B * H * 64 * npad * 2));
@@ -1114,7 +1114,7 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
     if (!q || !k || !v || !out || B <= 0 || N <= 0 || H <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    const int D = H * 64, M = B * N, npad = (N + 31) / 32 * 32;
+    const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
     // host-side packing into the layouts the QKV epilogue produces
     std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad, 0);
     for (int m = 0; m < M; ++m) {
@@ -1128,7 +1128,10 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
     HIPCHK(dqk.alloc(qk.size() * 2)); HIPCHK(dvt.alloc(vt.size() * 2)); HIPCHK(dout.alloc((size_t)M * D * 2));
     HIPCHK(hipMemcpy(dqk.p, qk.data(), qk.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dvt.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(launch_attention((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, nullptr));
+    {
+        const char* me = getenv("VT_ATTN_MODE");
+        HIPCHK(launch_attention_mode((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, me ? atoi(me) : -1, nullptr));
+    }
     HIPCHK(hipDeviceSynchronize());
     std::vector<bf16_t> tmp((size_t)M * D);
     HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));

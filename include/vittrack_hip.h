@@ -220,7 +220,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
                      float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
- * npad = tokens rounded up to 32, padding zero); bf16 results widened to f32. */
+ * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. */
 int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
                    float* qk_out, float* vt_out, int B, int tokens, int D);
 /* out[B,N,H*64] (bf16 widened to f32) = softmax(q k^T) v per head; q,k,v: [B,N,H*64] bf16 bits

@@ -104,9 +104,12 @@ def _attn_ref(q, k, v, B, N, H):
     return out
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0),
-                                         (1, 980, 16, 0.5), (1, 33, 1, 3.0)])
-def test_attention(gpu, B, N, H, scale):
+                                         (1, 980, 16, 0.5), (1, 33, 1, 3.0), (3, 100, 2, 1.0)])
+def test_attention(gpu, monkeypatch, B, N, H, scale, mode):
+    """mode 0: key-split waves, 1: independent waves, 2: K/Vt tiles shared through LDS"""
+    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     rng = np.random.default_rng(N + H)
     D = H * 64
     qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
@@ -120,7 +123,9 @@ def test_attention(gpu, B, N, H, scale):
     assert err.mean() < 2e-3
 
 
-def test_attention_exact_selector(gpu):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_attention_exact_selector(gpu, monkeypatch, mode):
+    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
     N, H = 96, 1
