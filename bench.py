@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=8, help="independent tracked streams per GPU")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="engines per GPU, each with streams/groups streams on its own HIP stream "
+                         "(kernels of different groups overlap on the chip)")
     ap.add_argument("--ring", type=int, default=64, help="distinct frames kept in HBM per clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -80,13 +83,19 @@ def main():
 
     # ---- weights: rank 0 generates/reads the blob, RCCL broadcast, every rank builds from HBM ----
     wpath = vt.weights.ensure_weights(cfg_name) if rank == 0 else None
+    G = args.groups
+    if B % G:
+        raise SystemExit("--streams must be a multiple of --groups")
+    Bg = B // G
     if world > 1:
         blob = vd.broadcast_weights(wpath, device=dev)
-        grp = vt.Group(n_streams=B, device=local, use_graph=not args.eager,
-                       device_blob=(blob.data_ptr(), blob.numel()))
+        grps = [vt.Group(n_streams=Bg, device=local, use_graph=not args.eager,
+                         device_blob=(blob.data_ptr(), blob.numel())) for _ in range(G)]
         del blob
     else:
-        grp = vt.Group(wpath, n_streams=B, device=local, use_graph=not args.eager)
+        grps = [vt.Group(wpath, n_streams=Bg, device=local, use_graph=not args.eager)
+                for _ in range(G)]
+    grp = grps[0]
     mi = grp.model_info()
 
     # ---- synthetic clip: R frames of a closed path, resident in HBM; stream i runs it with a phase
@@ -103,7 +112,18 @@ def main():
                                         base + ((t + phase[i]) % R) * fbytes + fw * fh, fw, fh)
                           for i in range(B)])
     for i in range(B):
-        grp.init_device(i, frames_at[0][i], vt.BBox.new(*sc.gt_box(phase[i])))
+        grps[i // Bg].init_device(i % Bg, frames_at[0][i], vt.BBox.new(*sc.gt_box(phase[i])))
+
+    def enqueue_all(t):
+        fr = frames_at[t % R]
+        for g in range(G):
+            grps[g].enqueue_device(fr[g * Bg:(g + 1) * Bg])
+
+    def wait_all():
+        res = []
+        for g in range(G):
+            res += grps[g].wait()
+        return res
 
     def barrier():
         if world > 1:
@@ -111,14 +131,14 @@ def main():
 
     # ---- warm-up (untimed), then exactly K timed steps -------------------------------------------
     for t in range(W):
-        grp.enqueue_device(frames_at[t % R])
-    grp.wait()
+        enqueue_all(t)
+    wait_all()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(W, W + K):
-        grp.enqueue_device(frames_at[t % R])
-    res = grp.wait()
+        enqueue_all(t)
+    res = wait_all()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -131,7 +151,7 @@ def main():
     t_last = W + K - 1
     ious, done, succ = [], [], []
     for i in range(B):
-        st = grp.read_state(i)
+        st = grps[i // Bg].read_state(i % Bg)
         done.append(st["frames_done"])
         succ.append(st["success_count"])
         ious.append(iou(res[i].bbox, sc.gt_box((t_last + phase[i]) % R)))
@@ -141,7 +161,8 @@ def main():
     lat = []
     for t in range(W + K, W + K + 50):
         a = time.perf_counter()
-        grp.update_device(frames_at[t % R])
+        enqueue_all(t)
+        wait_all()
         lat.append(time.perf_counter() - a)
     lat_ms = float(np.median(lat) * 1e3)
 
@@ -151,7 +172,7 @@ def main():
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": wl_text, "model": cfg_name, "frame": f"{fw}x{fh} NV12",
-                   "streams_per_gpu": B, "tokens": mi.tokens_template + mi.tokens_search,
+                   "streams_per_gpu": B, "engines_per_gpu": G, "tokens": mi.tokens_template + mi.tokens_search,
                    "ingest": "frames resident in HBM", "launch": "eager" if args.eager else "hipGraph",
                    "weights": "synthetic seeded encoder + fitted head (no reference weights exist)"},
         "per_stream_fps": fps / (world * B),
@@ -164,7 +185,7 @@ def main():
 
     # ---- per-kernel HIP-event timing on the library's stream -> roofline of the dominant kernel ------
     if not args.no_profile and rank == 0:
-        prof = grp.profile_device(frames_at[(W + K) % R], iters=5)
+        prof = grp.profile_device(frames_at[(W + K) % R][:Bg], iters=5)
         tot = sum(p["ms"] for p in prof)
         dom = max(prof, key=lambda p: p["ms"])
         gemm_ms = sum(p["ms"] for p in prof if p["name"].startswith("gemm"))

@@ -21,6 +21,8 @@
 //     that the store side is wide: f32 outputs keep the column on the lane (128 B contiguous per
 //     row per store), bf16 row-major outputs put the ROW on the lane so each lane owns 4
 //     consecutive columns per accumulator quad (one 8-B store).
+#include <cstdlib>
+
 #include "vt_common.hpp"
 
 #define GEMM_BK 64
@@ -60,30 +62,33 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NS, bool ROW_ON_LANE>
+template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
-                                              f32x16_t (&acc)[BM / 64][BN / 64]) {
-    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
-    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+                                              f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
+    constexpr int NW = WVM * WVN;               // waves per block
+    constexpr int WM = BM / WVM, WN = BN / WVN; // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave in each direction
+    constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);  // 1-KiB LDS-DMA pieces per wave
+    static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     constexpr int STAGE = (BM + BN) * ROW_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WVN, wc = wave % WVN;
     const int l31 = lane & 31, half = lane >> 5;
 
     // per-lane source pointers for the LDS-DMA pieces this wave issues (rows fixed over K)
-    const bf16_t* asrc[BM / 32];
-    const bf16_t* bsrc[BN / 32];
+    const bf16_t* asrc[PA];
+    const bf16_t* bsrc[PB];
 #pragma unroll
-    for (int j = 0; j < BM / 32; ++j) {
-        const int row = (wave * (BM / 32) + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PA; ++j) {
+        const int row = (wave * PA + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
         asrc[j] = p.A + (size_t)gm * p.lda + c * 8;
     }
 #pragma unroll
-    for (int j = 0; j < BN / 32; ++j) {
-        const int row = (wave * (BN / 32) + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PB; ++j) {
+        const int row = (wave * PB + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         bsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
     }
@@ -91,11 +96,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         char* sA = smem + buf * STAGE;
         char* sB = sA + BM * ROW_BYTES;
 #pragma unroll
-        for (int j = 0; j < BM / 32; ++j)
-            glds16(asrc[j] + kt * GEMM_BK, sA + (wave * (BM / 32) + j) * 8 * ROW_BYTES);
+        for (int j = 0; j < PA; ++j)
+            glds16(asrc[j] + kt * GEMM_BK, sA + (wave * PA + j) * 8 * ROW_BYTES);
 #pragma unroll
-        for (int j = 0; j < BN / 32; ++j)
-            glds16(bsrc[j] + kt * GEMM_BK, sB + (wave * (BN / 32) + j) * 8 * ROW_BYTES);
+        for (int j = 0; j < PB; ++j)
+            glds16(bsrc[j] + kt * GEMM_BK, sB + (wave * PB + j) * 8 * ROW_BYTES);
     };
 
     // fragment read offsets (bytes inside a stage), per k-step the chunk index changes by 2
@@ -113,7 +118,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         bswz[j] = (row >> 1) & 7;
     }
 
-    constexpr int IPS = BM / 32 + BN / 32;  // LDS-DMA instructions per wave per stage
+    constexpr int IPS = PA + PB;  // LDS-DMA instructions per wave per stage
     const int nk = p.K / GEMM_BK;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -156,15 +161,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     }
 }
 
-template <int BM, int BN, int NS, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
+__global__ __launch_bounds__(WVM * WVN * 64) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = BM / 64, TN = BN / 64, WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
     const int tiles_n = p.N / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2). Give each XCD
+    // a contiguous run of tiles (whole row panels of A, all of W) instead of every 8th tile, so
+    // its 4 MiB L2 holds its own slice of A plus W; otherwise every XCD streams all of A and W and
+    // the LDS-DMA loads run at the Infinity-Cache rate (~33 GB/s per CU instead of ~70). Speed
+    // only: any placement computes the same tile set (bijective for any grid size).
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int wr = wave / WVN, wc = wave % WVN, l31 = lane & 31, half = lane >> 5;
 
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        gemm_mainloop<BM, BN, NS, false>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                 }
             }
     } else if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
-        gemm_mainloop<BM, BN, NS, true>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * WM + i * 32 + l31;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         const int D = p.D;
         if (n0 < 2 * D) {
             // q (scaled by 1/8 = 1/sqrt(64), exact in bf16) and k: row-major [M][2D]
-            gemm_mainloop<BM, BN, NS, true>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
             const float sc = (n0 < D) ? 0.125f : 1.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         } else {
             // v: transposed per head, Vt[b][h][d][t] with t contiguous (npad per row), so the
             // attention kernel reads 4 consecutive keys of one d with one 8-B load
-            gemm_mainloop<BM, BN, NS, false>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
             const int heads = D >> 6;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -280,24 +295,42 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-// Tile configurations: {BM, BN, NS}. 64x64 with a 4-deep ring (64 KiB, two blocks per CU) for the
-// small-M shapes of one or a few streams; 128x128 with a 3-deep ring (96 KiB) once the grid fills
-// the chip several times over.
-template <int BM, int BN, int NS, int EPI>
+// Tile configurations {BM, BN, waves M x N, ring depth}:
+//   0: 64x64   2x2 ring 4    small M, long K (fc2 of one or two streams)
+//   1: 128x128 2x2 ring 3
+//   2: 64x64   2x2 ring 2    small M: most blocks per CU
+//   3: 128x128 2x2 ring 2
+//   4: 256x256 2x4 ring 2    128 KiB LDS, 8 waves, one block per CU: half the global->LDS bytes per
+//                            FLOP of 128x128, which is what bounds these GEMMs (profiles/README.md)
+//   5: 256x128 4x2 ring 2    96 KiB LDS, for N = 768 where 256-wide column tiles leave a ragged grid
+#define GEMM_FOR_EACH_CFG(X, EPI) \
+    X(0, 64, 64, 2, 2, 4, EPI)    \
+    X(1, 128, 128, 2, 2, 3, EPI)  \
+    X(2, 64, 64, 2, 2, 2, EPI)    \
+    X(3, 128, 128, 2, 2, 2, EPI)  \
+    X(4, 256, 256, 2, 4, 2, EPI)  \
+    X(5, 256, 128, 4, 2, 2, EPI)  \
+    X(6, 128, 128, 2, 4, 4, EPI)  \
+    X(7, 256, 128, 4, 2, 3, EPI)  \
+    X(8, 128, 128, 2, 4, 3, EPI)
+#define GEMM_NUM_CFG 9
+
+template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
     constexpr int smem = NS * (BM + BN) * ROW_BYTES;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NS, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 template <int EPI>
 static hipError_t prepare_epi() {
-    hipError_t e = prepare_cfg<128, 128, 3, EPI>();
-    if (e != hipSuccess) return e;
-    e = prepare_cfg<128, 128, 2, EPI>();
-    if (e != hipSuccess) return e;
-    e = prepare_cfg<64, 64, 2, EPI>();
-    return e != hipSuccess ? e : prepare_cfg<64, 64, 4, EPI>();
+    hipError_t e = hipSuccess;
+#define X(id, BM, BN, WVM, WVN, NS, E) \
+    if (e == hipSuccess) e = prepare_cfg<BM, BN, WVM, WVN, NS, E>();
+    GEMM_FOR_EACH_CFG(X, EPI)
+#undef X
+    return e;
 }
 
 // Raise the dynamic-LDS limit of every instantiation once per device, outside any stream capture.
@@ -311,20 +344,23 @@ hipError_t gemm_prepare() {
     return prepare_epi<EPI_F32>();
 }
 
-template <int BM, int BN, int NS, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = NS * (BM + BN) * ROW_BYTES;
+    if (a.N % BN != 0) return hipErrorInvalidValue;
+    if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NS, EPI>), dim3(tiles), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>), dim3(tiles),
+                       dim3(WVM * WVN * 64), smem, st, a);
     return hipGetLastError();
 }
 
-// 0: 64x64 ring 4, 1: 128x128 ring 3, 2: 64x64 ring 2, 3: 128x128 ring 2.
-// Chosen from a sweep on MI355X over the tracker's shapes (M = 720 * streams; profiles/
-// gemm_sweep_r01.txt): at these sizes the kernel is bound by global->LDS traffic and occupancy, not
-// by MFMA issue, so the small tile with two or more blocks per CU wins until the grid is several
-// waves deep; the deeper ring only pays for the long-K, small-M fc2.
+// Chosen from sweeps on MI355X over the tracker's shapes (M = 720 * streams; profiles/
+// gemm_sweep_r01.txt).
 int gemm_pick_config(int M, int N, int K, int epilogue) {
+    const char* env = getenv("VT_GEMM_CFG");   // tuning / test override
+    const int forced = env ? atoi(env) : -1;
+    if (forced >= 0 && forced < GEMM_NUM_CFG) return forced;
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
     switch (epilogue) {
@@ -338,26 +374,25 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
 }
 
 const char* gemm_config_name(int cfg) {
-    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
-    return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
+    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "256x256x2",
+                              "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3"};
+    return (cfg >= 0 && cfg < GEMM_NUM_CFG) ? n[cfg] : "?";
 }
 
 template <int EPI>
 static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
-        case 0: return launch_cfg<64, 64, 4, EPI>(a, st);
-        case 1: return launch_cfg<128, 128, 3, EPI>(a, st);
-        case 2: return launch_cfg<64, 64, 2, EPI>(a, st);
-        case 3: return launch_cfg<128, 128, 2, EPI>(a, st);
+#define X(id, BM, BN, WVM, WVN, NS, E) \
+    case id: return launch_cfg<BM, BN, WVM, WVN, NS, E>(a, st);
+        GEMM_FOR_EACH_CFG(X, EPI)
+#undef X
         default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st) {
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
-    if ((cfg == 1 || cfg == 3) && a.N % 128 != 0) return hipErrorInvalidValue;
-    if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0 ||
-                                ((cfg == 1 || cfg == 3) && a.D % 128 != 0)))
+    if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
         return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
@@ -371,5 +406,8 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {
-    return launch_gemm_cfg(a, epilogue, gemm_pick_config(a.M, a.N, a.K, epilogue), st);
+    int cfg = gemm_pick_config(a.M, a.N, a.K, epilogue);
+    hipError_t e = launch_gemm_cfg(a, epilogue, cfg, st);
+    if (e == hipErrorInvalidValue && cfg != 2) e = launch_gemm_cfg(a, epilogue, 2, st);  // shape does not fit the forced tile
+    return e;
 }

@@ -32,6 +32,44 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
+    """each tile configuration (64x64 .. 256x256, ring 2..4) on a ragged M, against float32 NumPy"""
+    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
+    rng = np.random.default_rng(cfg * 10 + epi)
+    M, N, K = 720 + 37, 768, 384
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.05)
+    bias = rng.standard_normal(N).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    z = a @ w.T + bias
+    got = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=epi)
+    if epi == 0:
+        assert np.abs(got - z).max() < 2e-3
+    elif epi == 1:
+        assert np.abs(got - (c0 + z)).max() < 2e-3
+    else:
+        ref = 0.5 * z * (1.0 + erf(z * 0.7071067811865476))
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_qkv_every_tile_config(gpu, monkeypatch, cfg):
+    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
+    rng = np.random.default_rng(cfg)
+    B, tokens, D = 2, 100, 768
+    ab, a = _rand_bf16(gpu, rng, (B * tokens, D))
+    wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
+    bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
+    z = a @ w.T + bias
+    qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
+    ref_qk = np.concatenate([z[:, :D] * 0.125, z[:, D:2 * D]], axis=1)
+    assert np.all(np.abs(qk - ref_qk) <= np.abs(ref_qk) * 2 ** -8 + 1e-3)
+    v = z[:, 2 * D:].reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
+    assert np.all(np.abs(vt_[:, :, :tokens] - v) <= np.abs(v) * 2 ** -8 + 1e-3)
+
+
 def test_gemm_exact_integers_asymmetric(gpu):
     """A = identity-like selector, W asymmetric small integers: catches swapped row/col maps and
     any staging/swizzle mix-up exactly (all values are exact in bf16 and f32)."""

@@ -2,13 +2,18 @@
 import sys
 sys.path.insert(0, '.')
 import gstreamer_vit_tracker_amd as vt
-names = {0: "64x64x4", 1: "128x128x3", 2: "64x64x2", 3: "128x128x2"}
+names = {0: "64x64x4", 1: "128x128x3", 2: "64x64x2", 3: "128x128x2", 4: "256x256x2", 5: "256x128x2",
+         6: "128x128w8x4", 7: "256x128x3", 8: "128x128w8x3"}
 epi_names = {1: "resid", 2: "gelu", 4: "qkv"}
-for B in (1, 2, 4, 8, 16):
+cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3, 4, 5]
+Bs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 8, 16, 32]
+for B in Bs:
     M = 720 * B
     for (N, K, epi) in [(2304, 768, 4), (768, 768, 1), (3072, 768, 2), (768, 3072, 1)]:
         row = []
-        for cfg in (0, 1, 2, 3):
+        for cfg in cfgs:
+            if cfg == 4 and N % 256:
+                continue
             us = vt.op_gemm_bench(M, N, K, epi, cfg, iters=30)
-            row.append(f"{names[cfg]} {us:7.1f}us {2.0*M*N*K/us/1e6:6.0f}TF")
+            row.append(f"{names[cfg]} {us:7.1f}us {2.0*M*N*K/us/1e6:5.0f}TF")
         print(f"B={B:2d} M={M:5d} N={N:4d} K={K:4d} {epi_names[epi]:5s} | " + " | ".join(row), flush=True)
