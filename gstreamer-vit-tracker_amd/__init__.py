@@ -77,7 +77,7 @@ EXPORTS = [
     "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
-    "vt_op_layernorm",
+    "vt_op_attention_bench", "vt_op_layernorm",
 ]
 
 
@@ -144,6 +144,7 @@ def lib():
     L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int]
     L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int]
+    L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
     _lib = L
     return L
@@ -459,6 +460,12 @@ def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0):
     _check(lib().vt_op_attention_bf16(device, _u16(q_bits), _u16(k_bits), _u16(v_bits), _f32(out),
                                       B, N, H))
     return out
+
+
+def op_attention_bench(B, N, H, mode=-1, iters=30, device=0) -> float:
+    us = c_float()
+    _check(lib().vt_op_attention_bench(device, B, N, H, mode, iters, byref(us)))
+    return float(us.value)
 
 
 def op_layernorm(x, gamma, beta, device=0):

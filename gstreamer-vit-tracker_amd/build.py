@@ -27,6 +27,9 @@ HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "vt_en
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",
              "-Wno-unused-function"]
+# fused multiply-add allowed where no bit-exact float spec applies (MFMA kernels' epilogues and
+# softmax); the pixel stage and the box decode keep one IEEE operation per source operation
+FAST_CONTRACT = {"k_gemm.hip", "k_attn.hip"}
 HOST_SOURCES = ["host_capi.cpp"]
 
 
@@ -56,7 +59,10 @@ def build_hip(force: bool = False, save_temps: bool = False) -> str:
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            cmd = [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]
+            flags = list(HIP_FLAGS)
+            if s in FAST_CONTRACT:
+                flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)

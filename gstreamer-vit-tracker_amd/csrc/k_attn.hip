@@ -34,8 +34,77 @@ __device__ __forceinline__ bf16x8_t ld16(const bf16_t* p) {
 __device__ __forceinline__ bf16x4_t ld8(const bf16_t* p) {
     return *reinterpret_cast<const bf16x4_t*>(p);
 }
-__device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+// combine a value with the same lane of the other wave half: v_permlane32_swap (no LDS round trip)
+__device__ __forceinline__ float other_half(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // r[0]: lanes 32-63 now hold the lower half's value; r[1]: lanes 0-31 hold the upper half's
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, other_half(v)); }
+__device__ __forceinline__ float xhalf_sum(float v) { return v + other_half(v); }
+
+
+// One 32-key sub-tile for one wave: s = S^T accumulator (key on the register axis, query on the
+// lane). Updates the running max / sum, rescales O only when the max moved, and multiplies P into
+// O^T. VALU budget matters here (the tile is 8 MFMAs): exp2 with the log2(e) factor folded into
+// one fma, hardware bf16 packing, and no O rescale while the running max is unchanged.
+#define ATT_LOG2E 1.4426950408889634f
+__device__ __forceinline__ void softmax_pv(f32x16_t s, const bf16x8_t (&vf)[2][2], f32x16_t& o0,
+                                           f32x16_t& o1, float& m_run, float& l_run) {
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+    mx = xhalf_max(mx);
+    if (!__all(mx <= m_run)) {          // some query's max grew: rescale (wave-uniform branch)
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * ATT_LOG2E);
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m_run = m_new;
+    }
+    const float mb = -m_run * ATT_LOG2E;
+    float p[16], psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], ATT_LOG2E, mb));
+        psum += p[r];
+    }
+    l_run += xhalf_sum(psum);
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        union { uint32_t u[4]; bf16x8_t v; } cv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv.u[e] = pack_bf16x2(p[8 * s2 + 2 * e], p[8 * s2 + 2 * e + 1]);
+        pf[s2] = cv.v;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s2], pf[s2], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s2], pf[s2], o1, 0, 0, 0);
+    }
+}
+
+// S^T tile = K_tile · Q^T (4 k-steps over d = 64). MASK: -inf on keys >= tokens (only the last
+// tile of a sequence is instantiated with MASK, so full tiles carry no compare/select work).
+template <bool MASK>
+__device__ __forceinline__ f32x16_t qk_scores(const bf16x8_t (&kf)[4], const bf16x8_t (&qf)[4],
+                                              int key0, int tokens, int half) {
+    const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                           0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16_t s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+    if (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+    }
+    return s;
+}
 
 struct KvFrag {
     bf16x8_t k[4];      // K rows of the tile, 4 k-steps over d
@@ -60,7 +129,7 @@ __device__ __forceinline__ void load_tile(KvFrag& f, const bf16_t* kbase, const 
 }
 
 template <bool KVSPLIT>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qk,
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out, int tokens,
                                                         int H, int npad) {
@@ -99,54 +168,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         const int ktn = (kt + kstep < nkt) ? kt + kstep : kt;
         load_tile(nxt, kbase, vbase, ktn, tokens, ld, npad, l31);
 
-        f32x16_t s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.k[ks], qf[ks], s, 0, 0, 0);
-
         // s[r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*half, query = this lane's
-        float mx = -1.0e30f;
-        if (kt * 32 + 32 > tokens) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kidx = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (kidx >= tokens) s[r] = -INFINITY;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.0f;
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = __expf(s[r] - m_new);
-            psum += p[r];
-        }
-        psum = xhalf_sum(psum);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-
-        bf16x8_t pf[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            union { uint32_t u[4]; bf16x8_t v; } cv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                cv.u[e] = pack_bf16x2(p[8 * s2 + 2 * e], p[8 * s2 + 2 * e + 1]);
-            pf[s2] = cv.v;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.v[0][s2], pf[s2], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.v[1][s2], pf[s2], o1, 0, 0, 0);
-        }
+        const f32x16_t s = (kt * 32 + 32 > tokens)
+                               ? qk_scores<true>(cur.k, qf, kt * 32, tokens, half)
+                               : qk_scores<false>(cur.k, qf, kt * 32, tokens, half);
+        softmax_pv(s, cur.v, o0, o1, m_run, l_run);
         cur = nxt;
     }
 
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #define ATT_V_STRIDE 136
 #define ATT_V_BYTES (64 * ATT_V_STRIDE)
 
-__global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
                                                             int H, int npad) {
@@ -244,37 +270,37 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __rest
     // staging: each thread moves two 16-B chunks of the K tile and two of the Vt tile
     const bf16_t* kg = qk + (size_t)b * tokens * ld + D + h * 64;
     const bf16_t* vg = vt + (size_t)(b * H + h) * 64 * npad;
-    int krow[2], kch[2], koff[2], voff[2];
-    const bf16_t* vsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 256 * j;
-        krow[j] = c >> 3;
-        kch[j] = c & 7;
-        koff[j] = krow[j] * 128 + ((kch[j] ^ ((krow[j] >> 1) & 7)) << 4);
-        voff[j] = (c >> 3) * ATT_V_STRIDE + (c & 7) * 16;
-        vsrc[j] = vg + (size_t)(c >> 3) * npad + (c & 7) * 8;
+    // chunk c = tid + 256 j (j = 0, 1): row c >> 3, 16-B piece c & 7. Named scalars, not arrays
+    // captured by a lambda: the latter kept the staging registers in scratch memory.
+    const int c0 = tid, c1 = tid + 256;
+    const int krow0 = c0 >> 3, krow1 = c1 >> 3, kch0 = c0 & 7, kch1 = c1 & 7;
+    const int koff0 = krow0 * 128 + ((kch0 ^ ((krow0 >> 1) & 7)) << 4);
+    const int koff1 = krow1 * 128 + ((kch1 ^ ((krow1 >> 1) & 7)) << 4);
+    const int voff0 = krow0 * ATT_V_STRIDE + kch0 * 16, voff1 = krow1 * ATT_V_STRIDE + kch1 * 16;
+    const bf16_t* vsrc0 = vg + (size_t)krow0 * npad + kch0 * 8;
+    const bf16_t* vsrc1 = vg + (size_t)krow1 * npad + kch1 * 8;
+    uint4 kreg0, kreg1, vreg0, vreg1;
+#define ATT_GLOAD(KT)                                                                        \
+    {                                                                                        \
+        int key_a = (KT) * ATT_KT + krow0, key_b = (KT) * ATT_KT + krow1;                    \
+        key_a = key_a < tokens ? key_a : tokens - 1;                                         \
+        key_b = key_b < tokens ? key_b : tokens - 1;                                         \
+        kreg0 = *reinterpret_cast<const uint4*>(kg + (size_t)key_a * ld + kch0 * 8);         \
+        kreg1 = *reinterpret_cast<const uint4*>(kg + (size_t)key_b * ld + kch1 * 8);         \
+        vreg0 = *reinterpret_cast<const uint4*>(vsrc0 + (KT) * ATT_KT);                      \
+        vreg1 = *reinterpret_cast<const uint4*>(vsrc1 + (KT) * ATT_KT);                      \
     }
-    uint4 kreg[2], vreg[2];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int key = kt * ATT_KT + krow[j];
-            key = key < tokens ? key : tokens - 1;
-            kreg[j] = *reinterpret_cast<const uint4*>(kg + (size_t)key * ld + kch[j] * 8);
-            vreg[j] = *reinterpret_cast<const uint4*>(vsrc[j] + kt * ATT_KT);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sk = smem + buf * (ATT_K_BYTES + ATT_V_BYTES);
-        char* sv = sk + ATT_K_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<uint4*>(sk + koff[j]) = kreg[j];
-            *reinterpret_cast<uint2*>(sv + voff[j]) = make_uint2(vreg[j].x, vreg[j].y);
-            *reinterpret_cast<uint2*>(sv + voff[j] + 8) = make_uint2(vreg[j].z, vreg[j].w);
-        }
-    };
+#define ATT_LSTORE(BUF)                                                                      \
+    {                                                                                        \
+        char* sk_ = smem + (BUF) * (ATT_K_BYTES + ATT_V_BYTES);                              \
+        char* sv_ = sk_ + ATT_K_BYTES;                                                       \
+        *reinterpret_cast<uint4*>(sk_ + koff0) = kreg0;                                      \
+        *reinterpret_cast<uint4*>(sk_ + koff1) = kreg1;                                      \
+        *reinterpret_cast<uint2*>(sv_ + voff0) = make_uint2(vreg0.x, vreg0.y);               \
+        *reinterpret_cast<uint2*>(sv_ + voff0 + 8) = make_uint2(vreg0.z, vreg0.w);           \
+        *reinterpret_cast<uint2*>(sv_ + voff1) = make_uint2(vreg1.x, vreg1.y);               \
+        *reinterpret_cast<uint2*>(sv_ + voff1 + 8) = make_uint2(vreg1.z, vreg1.w);           \
+    }
 
     f32x16_t o0, o1;
 #pragma unroll
@@ -282,11 +308,11 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __rest
     float m_run = -1.0e30f, l_run = 0.0f;
 
     const int nt = (tokens + ATT_KT - 1) / ATT_KT;
-    gload(0);
-    lstore(0);
+    ATT_GLOAD(0)
+    ATT_LSTORE(0)
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) gload(kt + 1);
+        if (kt + 1 < nt) ATT_GLOAD(kt + 1)
         const char* sk = smem + (kt & 1) * (ATT_K_BYTES + ATT_V_BYTES);
         const char* sv = sk + ATT_K_BYTES;
 #pragma unroll
@@ -309,50 +335,12 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __rest
                     const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(vp + 16);
                     vf[dc][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-            f32x16_t s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-            if (key0 + 32 > tokens) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
-            }
-            float mx = -1.0e30f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = xhalf_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
-            float psum = 0.0f, p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __expf(s[r] - m_new);
-                psum += p[r];
-            }
-            psum = xhalf_sum(psum);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            bf16x8_t pf[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                union { uint32_t u[4]; bf16x8_t v; } cv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    cv.u[e] = pack_bf16x2(p[8 * s2 + 2 * e], p[8 * s2 + 2 * e + 1]);
-                pf[s2] = cv.v;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s2], pf[s2], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s2], pf[s2], o1, 0, 0, 0);
-            }
+            const f32x16_t s = (key0 + 32 > tokens)
+                                   ? qk_scores<true>(kf, qf, key0, tokens, half)
+                                   : qk_scores<false>(kf, qf, key0, tokens, half);
+            softmax_pv(s, vf, o0, o1, m_run, l_run);
         }
-        if (kt + 1 < nt) lstore((kt + 1) & 1);
+        if (kt + 1 < nt) ATT_LSTORE((kt + 1) & 1)
         __syncthreads();
     }
 
@@ -377,10 +365,7 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const bf16_t* __rest
 hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                                  int H, int npad, int mode, hipStream_t st) {
     const int nqb = (tokens + 31) / 32;
-    if (mode < 0) {
-        const long wgs_lds = (long)((nqb + 3) / 4) * H * B;
-        mode = (wgs_lds >= 512 && npad % 64 == 0) ? 2 : 0;
-    }
+    if (mode < 0) mode = (npad % 64 == 0) ? 2 : 0;   // measured: the LDS-shared kernel wins at every batch
     if (mode == 2 && npad % 64 != 0) return hipErrorInvalidValue;
     if (mode == 0) {
         hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,

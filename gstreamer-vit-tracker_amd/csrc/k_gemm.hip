@@ -40,15 +40,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // the kernel at large tiles.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    float poly = 1.061405429f;
-    poly = poly * t + -1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t + -0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = 1.0f - (poly * t) * __expf(-z * z);   // erf(|x|/sqrt2)
-    const float erfv = x < 0.0f ? -e : e;
-    return 0.5f * x * (1.0f + erfv);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    // erf(|x|/sqrt2) = 1 - poly*t*exp(-z^2); exp(-z^2) = 2^(-z^2 log2 e)
+    const float g = poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erfv = __builtin_copysignf(1.0f - g, x);
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, erfv, hx);
 }
 
 // accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile
@@ -162,7 +163,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
 }
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
-__global__ __launch_bounds__(WVM * WVN * 64) void gemm_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
     const int tiles_n = p.N / BN;
@@ -218,79 +219,119 @@ __global__ __launch_bounds__(WVM * WVN * 64) void gemm_bf16_kernel(GemmArgs p) {
                     if (m < p.M) p.Cf[(size_t)m * p.ldc + n] = (acc[i][j][r] + bias) + addend[r];
                 }
             }
-    } else if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
-        gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wr * WM + i * 32 + l31;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * half;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][4 * q + e] + p.bias[n + e];
-                        v[e] = (EPI == EPI_GELU_BF16) ? gelu_erf(x) : fmaxf(x, 0.0f);
-                    }
-                    if (m < p.M) {
-                        uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                        *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldcb + n) = pk;
-                    }
-                }
+    } else {
+        // ---- bf16 outputs -----------------------------------------------------------------------
+        // The accumulator layout gives each lane 4 consecutive outputs (8 B) in 32 different rows;
+        // stored directly that is one 8-B L2 write request per lane (measured: as many L2 requests
+        // as all operand loads of the main loop together). Instead the block's output tile is
+        // assembled in LDS (the operand ring is dead by now) and written out as whole 16-B pieces
+        // of contiguous rows.
+        constexpr int NT = WVM * WVN * 64;
+        constexpr bool FITS = BM * (BN * 2 + 16) <= NS * (BM + BN) * ROW_BYTES &&
+                              BN * (BM * 2 + 16) <= NS * (BM + BN) * ROW_BYTES;
+        bool v_tile = false;        // QKV: this column tile holds V (stored transposed)
+        float scale = 1.0f;
+        if constexpr (EPI == EPI_QKV) {
+            v_tile = n0 >= 2 * p.D;
+            scale = (n0 < p.D) ? 0.125f : 1.0f;   // q * 1/sqrt(64), exact in bf16
         }
-    } else {  // EPI_QKV
-        const int D = p.D;
-        if (n0 < 2 * D) {
-            // q (scaled by 1/8 = 1/sqrt(64), exact in bf16) and k: row-major [M][2D]
+        if (!v_tile) {
+            // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
             gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
-            const float sc = (n0 < D) ? 0.125f : 1.0f;
+            constexpr int STRIDE = BN * 2 + 16;
+            if constexpr (FITS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wr * WM + i * 32 + l31;
+                const int mr = wr * WM + i * 32 + l31;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + wc * WN + j * 32 + 8 * q + 4 * half;
+                        const int nr = wc * WN + j * 32 + 8 * q + 4 * half;
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = (acc[i][j][4 * q + e] + p.bias[n + e]) * sc;
-                        if (m < p.M) {
-                            uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]),
-                                                  pack_bf16x2(v[2], v[3]));
-                            *reinterpret_cast<uint2*>(p.qk + (size_t)m * (2 * D) + n) = pk;
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = acc[i][j][4 * q + e] + p.bias[n0 + nr + e];
+                            if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);
+                            else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
+                            else v[e] = x * scale;
+                        }
+                        const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        if constexpr (FITS) {
+                            *reinterpret_cast<uint2*>(smem + mr * STRIDE + nr * 2) = pk;
+                        } else if (m0 + mr < p.M) {
+                            bf16_t* dst = (EPI == EPI_QKV)
+                                              ? p.qk + (size_t)(m0 + mr) * (2 * p.D) + n0 + nr
+                                              : p.Cb + (size_t)(m0 + mr) * p.ldcb + n0 + nr;
+                            *reinterpret_cast<uint2*>(dst) = pk;
                         }
                     }
             }
-        } else {
-            // v: transposed per head, Vt[b][h][d][t] with t contiguous (npad per row), so the
-            // attention kernel reads 4 consecutive keys of one d with one 8-B load
+            if constexpr (FITS) {
+                __syncthreads();
+                constexpr int CH = BN / 8;   // 16-B pieces per row
+                for (int c = threadIdx.x; c < BM * CH; c += NT) {
+                    const int r = c / CH, ch = c % CH;
+                    if (m0 + r < p.M) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(smem + r * STRIDE + ch * 16);
+                        bf16_t* dst = (EPI == EPI_QKV)
+                                          ? p.qk + (size_t)(m0 + r) * (2 * p.D) + n0 + ch * 8
+                                          : p.Cb + (size_t)(m0 + r) * p.ldcb + n0 + ch * 8;
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    }
+                }
+            }
+        } else if constexpr (EPI == EPI_QKV) {
+            // V, transposed per head: Vt[b][h][d][t] with t contiguous (npad per row). MFMA with the
+            // column (d) on the lane, 4 consecutive tokens per register quad.
             gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
-            const int heads = D >> 6;
+            constexpr int STRIDE = BM * 2 + 16;
+            const int heads = p.D >> 6;
+            if constexpr (FITS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wc * WN + j * 32 + l31;
-                    const float bias = p.bias[n];
-                    const int nv = n - 2 * D, hh = nv >> 6, d = nv & 63;
+                    const int nr = wc * WN + j * 32 + l31;
+                    const float bias = p.bias[n0 + nr];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int m = m0 + wr * WM + i * 32 + 8 * q + 4 * half;
-                        if (m < p.M) {
+                        const int mr = wr * WM + i * 32 + 8 * q + 4 * half;
+                        const uint2 pk = make_uint2(
+                            pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
+                            pack_bf16x2(acc[i][j][4 * q + 2] + bias, acc[i][j][4 * q + 3] + bias));
+                        if constexpr (FITS) {
+                            *reinterpret_cast<uint2*>(smem + nr * STRIDE + mr * 2) = pk;
+                        } else if (m0 + mr < p.M) {
+                            const int m = m0 + mr, nv = n0 + nr - 2 * p.D;
                             const int b = m / p.tokens, t = m % p.tokens;
-                            uint2 pk = make_uint2(
-                                pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
-                                pack_bf16x2(acc[i][j][4 * q + 2] + bias,
-                                            acc[i][j][4 * q + 3] + bias));
-                            bf16_t* dst = p.vt + ((size_t)(b * heads + hh) * 64 + d) * p.npad + t;
+                            bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
                             *reinterpret_cast<uint2*>(dst) = pk;
                         }
                     }
                 }
+            if constexpr (FITS) {
+                __syncthreads();
+                constexpr int CH = BM / 8;   // 16-B pieces (8 tokens) per d-row
+                for (int c = threadIdx.x; c < BN * CH; c += NT) {
+                    const int r = c / CH, ch = c % CH;
+                    const int m = m0 + ch * 8, nv = n0 + r - 2 * p.D;
+                    if (m >= p.M) continue;
+                    const int b = m / p.tokens, t = m % p.tokens;
+                    bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
+                    const char* src = smem + r * STRIDE + ch * 16;
+                    if (t + 8 <= p.tokens && m + 8 <= p.M && ((t & 7) == 0)) {
+                        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                    } else {
+                        // the piece straddles a stream boundary (tokens % 8 != 0) or the end of M
+                        for (int e = 0; e < 8 && m + e < p.M; ++e) {
+                            const int me = m + e, be = me / p.tokens, te = me % p.tokens;
+                            p.vt[((size_t)(be * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + te] =
+                                *reinterpret_cast<const bf16_t*>(src + 2 * e);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -364,7 +405,8 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
     switch (epilogue) {
-        case EPI_QKV: return (n128 && tiles128 >= 400) ? 3 : 2;
+        case EPI_QKV:
+        case EPI_GELU_BF16: return (n128 && tiles128 >= 400) ? 3 : 2;
         case EPI_RESID:
             if (K >= 2048 && M <= 2048) return 0;
             if (K >= 2048 && n128 && tiles128 >= 256) return 3;

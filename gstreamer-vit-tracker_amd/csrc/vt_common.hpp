@@ -107,13 +107,15 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t st);
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) {
     return __uint_as_float(((uint32_t)b) << 16);
 }
-// round to nearest even; NaN kept a NaN (plain cast path is not used so that host/device agree)
+// f32 -> bf16, round to nearest even, NaN kept a NaN: one v_cvt_pk_bf16_f32 (gfx950). Same
+// result as the integer rounding (u + 0x7fff + ((u >> 16) & 1)) >> 16 of the oracle for every
+// finite input.
+typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+typedef float f32v2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32v2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }

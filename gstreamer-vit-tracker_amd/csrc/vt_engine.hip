@@ -1139,6 +1139,38 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
     return VT_OK;
 }
 
+// Timing helper: mean microseconds per launch of the attention kernel (mode as VT_ATTN_MODE, <0 =
+// the launcher's choice) on device-resident random data.
+int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out) {
+    if (B <= 0 || N <= 0 || H <= 0 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
+    std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad);
+    uint32_t seed = 777u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (bf16_t)(0x3c00u + ((seed >> 9) & 0x3ffu) + ((seed >> 3) & 0x8000u)); };
+    for (auto& v : qk) v = rnd();
+    for (auto& v : vt) v = rnd();
+    DevBuf dqk, dvt, dout;
+    HIPCHK(dqk.alloc(qk.size() * 2)); HIPCHK(dvt.alloc(vt.size() * 2)); HIPCHK(dout.alloc((size_t)M * D * 2));
+    HIPCHK(hipMemcpy(dqk.p, qk.data(), qk.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dvt.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+    for (int i = 0; i < 3; ++i)
+        HIPCHK(launch_attention_mode((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, mode, nullptr));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i)
+        HIPCHK(launch_attention_mode((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, mode, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_out = ms * 1000.0f / iters;
+    return VT_OK;
+}
+
 int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta, float* y, int M, int D) {
     if (!x || !gamma || !beta || !y || M <= 0 || D % 128) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;

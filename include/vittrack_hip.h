@@ -227,6 +227,9 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
  * (q already scaled). */
 int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v,
                          float* out, int B, int N, int H);
+/* Kernel-tuning helper: mean microseconds per launch of the attention kernel on random data;
+ * mode 0 key-split, 1 independent waves, 2 LDS-shared tiles, <0 the launcher's choice. */
+int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out);
 /* y[M,D] (bf16 widened) = LayerNorm(x[M,D] f32; gamma, beta, eps=1e-6) */
 int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta,
                     float* y, int M, int D);
