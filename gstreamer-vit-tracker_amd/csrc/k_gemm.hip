@@ -162,6 +162,124 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     }
 }
 
+// Register-staged variant of the main loop (two LDS buffers): the global loads of K-tile t+1 are
+// issued as ordinary 16-B loads into registers BEFORE tile t is computed and written to the other
+// LDS buffer after it (one barrier per tile). Same LDS image and fragment reads as the LDS-DMA
+// loop. Why it exists: one global_load_lds costs the issuing wave ~60-180 cycles of issue time; at
+// 8 pieces per wave per K-tile that is more than the 512 MFMA cycles of the tile itself, whereas a
+// global_load_dwordx4 + ds_write_b128 pair costs ~20.
+template <int BM, int BN, int WVM, int WVN, bool ROW_ON_LANE>
+__device__ __forceinline__ void gemm_mainloop_rs(const GemmArgs& p, char* smem, int m0, int n0,
+                                                 f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
+    constexpr int NT = WVM * WVN * 64;
+    constexpr int WM = BM / WVM, WN = BN / WVN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-B chunks per thread per tile
+    static_assert(CA >= 1 && CB >= 1, "tile too small");
+    constexpr int STAGE = (BM + BN) * ROW_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WVN, wc = wave % WVN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // chunk c = tid + NT*j of a tile: row c >> 3, 16-B piece c & 7 (recomputed where used: arrays
+    // of per-chunk pointers/registers would be left in scratch memory by the compiler)
+    typedef uint32_t rega_t __attribute__((ext_vector_type(4 * CA)));
+    typedef uint32_t regb_t __attribute__((ext_vector_type(4 * CB)));
+    const int row0 = tid >> 3, ch0 = tid & 7;           // chunk j: row0 + j*NT/8, same piece
+    const int swz_dst0 = row0 * ROW_BYTES;
+    int aoff[TM], boff[TN], aswz[TM], bswz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wr * WM + i * 32 + l31;
+        aoff[i] = row * ROW_BYTES;
+        aswz[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 32 + l31;
+        boff[j] = BM * ROW_BYTES + row * ROW_BYTES;
+        bswz[j] = (row >> 1) & 7;
+    }
+
+    const int nk = p.K / GEMM_BK;
+    rega_t ra;
+    regb_t rb;
+    (void)swz_dst0;
+#define RS_LOAD(KT)                                                                              \
+    {                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < CA; ++j) {                                         \
+            const int row = row0 + j * (NT / 8);                                                 \
+            int gm = m0 + row;                                                                   \
+            gm = gm < p.M ? gm : p.M - 1;                                                        \
+            const uint4 t = *reinterpret_cast<const uint4*>(p.A + (size_t)gm * p.lda + ch0 * 8 + \
+                                                            (KT) * GEMM_BK);                     \
+            ra[4 * j] = t.x; ra[4 * j + 1] = t.y; ra[4 * j + 2] = t.z; ra[4 * j + 3] = t.w;      \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                         \
+            const int row = row0 + j * (NT / 8);                                                 \
+            const uint4 t = *reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + row) * p.ldw +   \
+                                                            ch0 * 8 + (KT) * GEMM_BK);           \
+            rb[4 * j] = t.x; rb[4 * j + 1] = t.y; rb[4 * j + 2] = t.z; rb[4 * j + 3] = t.w;      \
+        }                                                                                        \
+    }
+#define RS_STORE(BUF)                                                                            \
+    {                                                                                            \
+        char* sdst = smem + (BUF) * STAGE;                                                       \
+        _Pragma("unroll") for (int j = 0; j < CA; ++j) {                                         \
+            const int row = row0 + j * (NT / 8);                                                 \
+            *reinterpret_cast<uint4*>(sdst + row * ROW_BYTES + ((ch0 ^ ((row >> 1) & 7)) << 4)) = \
+                make_uint4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);              \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                         \
+            const int row = row0 + j * (NT / 8);                                                 \
+            *reinterpret_cast<uint4*>(sdst + (BM + row) * ROW_BYTES +                            \
+                                      ((ch0 ^ ((row >> 1) & 7)) << 4)) =                        \
+                make_uint4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);              \
+        }                                                                                        \
+    }
+    RS_LOAD(0)
+    RS_STORE(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) RS_LOAD(kt + 1)
+        const char* sbase = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af[TM], bfr[TN];
+            const int c = 2 * ks + half;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((c ^ aswz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((c ^ bswz[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (ROW_ON_LANE)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i],
+                                                                            acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j],
+                                                                            acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) RS_STORE(cur ^ 1)
+        __syncthreads();
+    }
+}
+
+// NS > 0: LDS-DMA ring of NS stages; NS == -2: register-staged double buffer
+template <int BM, int BN, int WVM, int WVN, int NS, bool ROL>
+__device__ __forceinline__ void run_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
+                                             f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
+    if constexpr (NS > 0) gemm_mainloop<BM, BN, WVM, WVN, NS, ROL>(p, smem, m0, n0, acc);
+    else gemm_mainloop_rs<BM, BN, WVM, WVN, ROL>(p, smem, m0, n0, acc);
+}
+
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,7 +309,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+        run_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -227,8 +345,9 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         // assembled in LDS (the operand ring is dead by now) and written out as whole 16-B pieces
         // of contiguous rows.
         constexpr int NT = WVM * WVN * 64;
-        constexpr bool FITS = BM * (BN * 2 + 16) <= NS * (BM + BN) * ROW_BYTES &&
-                              BN * (BM * 2 + 16) <= NS * (BM + BN) * ROW_BYTES;
+        constexpr int NSA = NS > 0 ? NS : -NS;
+        constexpr bool FITS = BM * (BN * 2 + 16) <= NSA * (BM + BN) * ROW_BYTES &&
+                              BN * (BM * 2 + 16) <= NSA * (BM + BN) * ROW_BYTES;
         bool v_tile = false;        // QKV: this column tile holds V (stored transposed)
         float scale = 1.0f;
         if constexpr (EPI == EPI_QKV) {
@@ -237,7 +356,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
-            gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
+            run_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
 #pragma unroll
@@ -284,7 +403,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t] with t contiguous (npad per row). MFMA with the
             // column (d) on the lane, 4 consecutive tokens per register quad.
-            gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+            run_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BM * 2 + 16;
             const int heads = p.D >> 6;
             if constexpr (FITS) __syncthreads();
@@ -353,12 +472,16 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(5, 256, 128, 4, 2, 2, EPI)  \
     X(6, 128, 128, 2, 4, 4, EPI)  \
     X(7, 256, 128, 4, 2, 3, EPI)  \
-    X(8, 128, 128, 2, 4, 3, EPI)
-#define GEMM_NUM_CFG 9
+    X(8, 128, 128, 2, 4, 3, EPI)  \
+    X(9, 128, 128, 2, 2, -2, EPI) \
+    X(10, 64, 64, 2, 2, -2, EPI)  \
+    X(11, 256, 256, 2, 4, -2, EPI) \
+    X(12, 256, 128, 4, 2, -2, EPI)
+#define GEMM_NUM_CFG 13
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
-    constexpr int smem = NS * (BM + BN) * ROW_BYTES;
+    constexpr int smem = (NS > 0 ? NS : -NS) * (BM + BN) * ROW_BYTES;
     return hipFuncSetAttribute(
         reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -387,7 +510,7 @@ hipError_t gemm_prepare() {
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = NS * (BM + BN) * ROW_BYTES;
+    constexpr int smem = (NS > 0 ? NS : -NS) * (BM + BN) * ROW_BYTES;
     if (a.N % BN != 0) return hipErrorInvalidValue;
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
@@ -417,7 +540,8 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
 
 const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "256x256x2",
-                              "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3"};
+                              "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3", "128x128rs",
+                              "64x64rs", "256x256rs", "256x128rs"};
     return (cfg >= 0 && cfg < GEMM_NUM_CFG) ? n[cfg] : "?";
 }
 
