@@ -19,7 +19,7 @@ from . import weights  # noqa: F401  (blob writer / configs)
 from . import synth    # noqa: F401
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libvittrack_hip.so")
+LIB_PATH = os.environ.get("VITTRACK_HIP_LIB", os.path.join(PKG_DIR, "libvittrack_hip.so"))
 
 PIX_RGB8, PIX_NV12 = 0, 1
 
@@ -56,7 +56,8 @@ class CModelInfo(Structure):
 class CFrame(Structure):
     _fields_ = [("plane0", c_void_p), ("plane1", c_void_p), ("width", c_int32),
                 ("height", c_int32), ("stride0", c_int32), ("stride1", c_int32),
-                ("format", c_int32), ("reserved", c_int32)]
+                ("format", c_int32), ("origin_x", c_int32), ("origin_y", c_int32),
+                ("reserved", c_int32)]
 
 
 class CKernelTime(Structure):
@@ -309,11 +310,11 @@ class VitTrack:
 
 
 def frame_nv12(d_y, d_uv, w, h, y_stride=None, uv_stride=None) -> CFrame:
-    return CFrame(d_y, d_uv, w, h, y_stride or w, uv_stride or ((w + 1) & ~1), PIX_NV12, 0)
+    return CFrame(d_y, d_uv, w, h, y_stride or w, uv_stride or ((w + 1) & ~1), PIX_NV12, 0, 0, 0)
 
 
 def frame_rgb8(d_rgb, w, h, stride=None) -> CFrame:
-    return CFrame(d_rgb, None, w, h, stride or 3 * w, 0, PIX_RGB8, 0)
+    return CFrame(d_rgb, None, w, h, stride or 3 * w, 0, PIX_RGB8, 0, 0, 0)
 
 
 class Group:

@@ -134,28 +134,53 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         // every wave's pieces of tile kt are in LDS, and every wave has finished reading the
         // stage of tile kt-1, which the next prefetch overwrites
         __builtin_amdgcn_s_barrier();
+#if !defined(VT_ABLATE) || VT_ABLATE != 1   /* 1: no operand loads after the prologue */
         if (kt + NS - 1 < nk) stage(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+#endif
         const char* sbase = smem + cur * STAGE;
+#if defined(VT_ABLATE) && VT_ABLATE == 3     /* 3: loads and barriers only */
+        asm volatile("" ::"v"(sbase));
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        continue;
+#endif
+        // k-steps software-pipelined inside the wave: the fragments of step ks+1 are read from LDS
+        // while the MFMAs of step ks issue (the compiler then waits with a counted lgkmcnt instead
+        // of draining every read before every MFMA group)
+        bf16x8_t af[2][TM], bfr[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[0][i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((half ^ aswz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((half ^ bswz[j]) << 4));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t af[TM], bfr[TN];
-            const int c = 2 * ks + half;
+            const int cb = ks & 1, nb = cb ^ 1;
+            if (ks < 3) {
+                const int c = 2 * (ks + 1) + half;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((c ^ aswz[i]) << 4));
+                for (int i = 0; i < TM; ++i)
+                    af[nb][i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] +
+                                                                   ((c ^ aswz[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((c ^ bswz[j]) << 4));
+                for (int j = 0; j < TN; ++j)
+                    bfr[nb][j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] +
+                                                                    ((c ^ bswz[j]) << 4));
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+#if defined(VT_ABLATE) && VT_ABLATE == 2     /* 2: LDS reads but no MFMA */
+                    asm volatile("" ::"v"(af[cb][i]), "v"(bfr[cb][j]));
+#else
                     if (ROW_ON_LANE)  // D[n][m]: lane = m (row of C), registers = n
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i],
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][j], af[cb][i],
                                                                             acc[i][j], 0, 0, 0);
                     else              // D[m][n]: lane = n (column of C), registers = m
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j],
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][i], bfr[cb][j],
                                                                             acc[i][j], 0, 0, 0);
+#endif
                 }
         }
         cur = (cur + 1 == NS) ? 0 : cur + 1;

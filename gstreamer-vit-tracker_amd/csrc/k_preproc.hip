@@ -86,12 +86,13 @@ __device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, fl
         return;
     }
     int r, g, b;
+    const int sx = px - f.x0, sy = py - f.y0;   // position inside the stored window
     if (f.fmt == VT_PIX_RGB8) {
-        const uint8_t* p = f.p0 + (size_t)py * f.s0 + (size_t)px * 3;
+        const uint8_t* p = f.p0 + (size_t)sy * f.s0 + (size_t)sx * 3;
         r = p[0]; g = p[1]; b = p[2];
     } else {
-        const int y = f.p0[(size_t)py * f.s0 + px];
-        const uint8_t* uv = f.p1 + (size_t)(py >> 1) * f.s1 + (px & ~1);
+        const int y = f.p0[(size_t)sy * f.s0 + sx];
+        const uint8_t* uv = f.p1 + (size_t)(sy >> 1) * f.s1 + (sx & ~1);   // x0, y0 even
         yuv_to_rgb(y, uv[0], uv[1], r, g, b);
     }
     rgb[0] = (float)r; rgb[1] = (float)g; rgb[2] = (float)b;

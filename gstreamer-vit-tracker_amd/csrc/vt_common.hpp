@@ -15,7 +15,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 struct FrameDesc {
     const uint8_t* p0;  // RGB8 packed pixels or NV12 Y plane
     const uint8_t* p1;  // NV12 interleaved UV plane
-    int32_t w, h, s0, s1, fmt, pad;
+    int32_t w, h, s0, s1, fmt;
+    int32_t x0, y0;     // frame coordinates of the first stored pixel (window upload)
+    int32_t pad;
 };
 
 // per tracked stream, lives in HBM; the decode kernel of frame t writes what the preprocessing

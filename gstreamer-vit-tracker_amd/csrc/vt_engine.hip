@@ -115,7 +115,9 @@ struct Engine {
     hipGraphExec_t graph_exec = nullptr;
     // host-pointer staging (single-stream API)
     uint8_t* d_stage = nullptr;
+    uint8_t* h_pack = nullptr;      // pinned: the window of a host frame, packed
     size_t stage_bytes = 0;
+    StreamState* h_states_all = nullptr;  // pinned mirror of d_states after the last pass
     int max_w = 3840, max_h = 2160;
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
@@ -152,6 +154,8 @@ void Engine::destroy() {
     if (h_frames) (void)hipHostFree(h_frames);
     if (h_results) (void)hipHostFree(h_results);
     if (h_state) (void)hipHostFree(h_state);
+    if (h_pack) (void)hipHostFree(h_pack);
+    if (h_states_all) (void)hipHostFree(h_states_all);
     for (int i = 0; i < RING; ++i)
         if (ring_ev[i]) (void)hipEventDestroy(ring_ev[i]);
     if (stream) (void)hipStreamDestroy(stream);
@@ -293,6 +297,8 @@ int Engine::alloc_buffers() {
     HIPCHK(hipHostMalloc((void**)&h_frames, sizeof(FrameDesc) * B * RING));
     HIPCHK(hipHostMalloc((void**)&h_results, sizeof(vt_result) * B));
     HIPCHK(hipHostMalloc((void**)&h_state, sizeof(StreamState)));
+    HIPCHK(hipHostMalloc((void**)&h_states_all, sizeof(StreamState) * B));
+    memset(h_states_all, 0, sizeof(StreamState) * B);
     memset(h_results, 0, sizeof(vt_result) * B);
     for (int i = 0; i < RING; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
     h_initialized.assign(B, 0);
@@ -439,6 +445,7 @@ int Engine::run_pass(Profiler* prof) {
     if (lerr != hipSuccess)
         return set_err(VT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
     HIPCHK(hipMemcpyAsync(h_results, d_results, sizeof(vt_result) * B, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_states_all, d_states, sizeof(StreamState) * B, hipMemcpyDeviceToHost, stream));
     return VT_OK;
 }
 
@@ -460,14 +467,18 @@ int Engine::capture_graph() {
 static int check_frame(const vt_frame& f) {
     if (!f.plane0 || f.width < 16 || f.height < 16 || f.width > 16384 || f.height > 16384)
         return set_err(VT_ERR_INVALID_ARG, "frame: null plane or size out of range");
+    const bool window = f.origin_x != 0 || f.origin_y != 0 || f.reserved == 1;  // strides cover the window only
     if (f.format == VT_PIX_RGB8) {
-        if (f.stride0 < f.width * 3) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
+        if (f.stride0 < (window ? 6 : f.width * 3)) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
     } else if (f.format == VT_PIX_NV12) {
-        if (!f.plane1 || f.stride0 < f.width || f.stride1 < ((f.width + 1) & ~1))
+        if (!f.plane1 || f.stride0 < (window ? 2 : f.width) || f.stride1 < (window ? 2 : ((f.width + 1) & ~1)))
             return set_err(VT_ERR_INVALID_ARG, "nv12: null UV plane or stride too small");
     } else {
         return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", f.format);
     }
+    if (f.origin_x < 0 || f.origin_y < 0 || f.origin_x >= f.width || f.origin_y >= f.height ||
+        (f.format == VT_PIX_NV12 && ((f.origin_x | f.origin_y) & 1)))
+        return set_err(VT_ERR_INVALID_ARG, "frame window origin %d,%d invalid", f.origin_x, f.origin_y);
     return VT_OK;
 }
 
@@ -475,6 +486,7 @@ static void to_desc(const vt_frame& f, FrameDesc* o) {
     o->p0 = (const uint8_t*)f.plane0;
     o->p1 = (const uint8_t*)f.plane1;
     o->w = f.width; o->h = f.height; o->s0 = f.stride0; o->s1 = f.stride1; o->fmt = f.format;
+    o->x0 = f.origin_x; o->y0 = f.origin_y;
     o->pad = 0;
 }
 
@@ -498,6 +510,7 @@ int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
     HIPCHK(hipMemcpyAsync(d_frames + b, slot, sizeof(FrameDesc), hipMemcpyHostToDevice, stream));
     HIPCHK(launch_preproc(d_frames, d_states, d_patches, d, b, 1, true, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    h_states_all[b] = *h_state;
     h_initialized[b] = 1;
     return VT_OK;
 }
@@ -825,36 +838,65 @@ int vt_get_model_info(const vt_tracker* t, vt_model_info* out) {
     return VT_OK;
 }
 
-// copy a host frame into the engine's staging buffer (tight rows) and describe it
+// Host-pointer ingest: only the window of the frame that the call can sample is uploaded. The
+// reference hands over the whole frame (6.2 MB of RGB8 at 1080p, src/pipeline.rs:105-112) although
+// the tracker reads a window of side 4*sqrt(w*h) around the last box; that window is packed into a
+// pinned buffer on the host (a few hundred KB) and copied asynchronously ahead of the kernels.
+// The caller's buffer is no longer referenced when this returns (src/pipeline.rs:125 draws into it).
 static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
-                            int s0, int s1, vt_frame* f) {
+                            int s0, int s1, const float* box, vt_frame* f) {
     if (!p0 || w < 16 || h < 16) return set_err(VT_ERR_INVALID_ARG, "null frame or size < 16");
     if (w > e->max_w || h > e->max_h)
         return set_err(VT_ERR_INVALID_ARG, "frame %dx%d exceeds configured max %dx%d", w, h, e->max_w, e->max_h);
-    HIPCHK(hipSetDevice(e->device));
-    const size_t need = (size_t)e->max_w * e->max_h * 3 + 256;
-    if (!e->d_stage) {
-        HIPCHK(hipMalloc((void**)&e->d_stage, need));
-        e->stage_bytes = need;
-    }
-    // the previous pass has finished reading the staging buffer: every sync call waits
-    memset(f, 0, sizeof(*f));
-    f->width = w; f->height = h; f->format = fmt;
     if (fmt == VT_PIX_RGB8) {
         if (s0 < 3 * w) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
-        HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)w * 3, p0, (size_t)s0, (size_t)w * 3, h,
-                                hipMemcpyHostToDevice, e->stream));
-        f->plane0 = e->d_stage; f->stride0 = w * 3;
-    } else {
-        if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
-        const int uvw = (w + 1) & ~1, uvh = (h + 1) / 2;
-        uint8_t* duv = e->d_stage + (((size_t)w * h + 255) & ~(size_t)255);
-        HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)w, p0, (size_t)s0, (size_t)w, h, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpy2DAsync(duv, (size_t)uvw, p1, (size_t)s1, (size_t)uvw, uvh, hipMemcpyHostToDevice, e->stream));
-        f->plane0 = e->d_stage; f->plane1 = duv; f->stride0 = w; f->stride1 = uvw;
+    } else if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) {
+        return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
     }
-    // the caller may overwrite its buffer as soon as we return (src/pipeline.rs:125)
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipSetDevice(e->device));
+    const size_t need = (size_t)e->max_w * e->max_h * 3 + 4096;
+    if (!e->d_stage) {
+        HIPCHK(hipMalloc((void**)&e->d_stage, need));
+        HIPCHK(hipHostMalloc((void**)&e->h_pack, need));
+        e->stage_bytes = need;
+    }
+    // window = search crop (factor 4; it contains the factor-2 template crop) + bilinear margin
+    const float side = 4.0f * sqrtf(fmaxf(box[2] * box[3], 1.0f));
+    const float cx = box[0] + 0.5f * box[2], cy = box[1] + 0.5f * box[3];
+    long x_lo = (long)floorf(cx - 0.5f * side) - 4, x_hi = (long)ceilf(cx + 0.5f * side) + 4;
+    long y_lo = (long)floorf(cy - 0.5f * side) - 4, y_hi = (long)ceilf(cy + 0.5f * side) + 4;
+    x_lo = std::max(0L, std::min((long)w, x_lo)) & ~1L;
+    y_lo = std::max(0L, std::min((long)h, y_lo)) & ~1L;
+    x_hi = std::max(x_lo, std::min((long)w, (x_hi + 1) & ~1L));
+    y_hi = std::max(y_lo, std::min((long)h, (y_hi + 1) & ~1L));
+    if (x_hi - x_lo < 2 || y_hi - y_lo < 2) {   // window misses the frame: nothing can be sampled
+        x_lo = 0; y_lo = 0; x_hi = 2; y_hi = 2;
+    }
+    const int ww = (int)(x_hi - x_lo), wh = (int)(y_hi - y_lo);
+    memset(f, 0, sizeof(*f));
+    f->width = w; f->height = h; f->format = fmt;
+    f->origin_x = (int)x_lo; f->origin_y = (int)y_lo;
+    f->reserved = 1;   // strides describe the packed window
+    size_t bytes;
+    if (fmt == VT_PIX_RGB8) {
+        const size_t rb = (size_t)ww * 3;
+        for (int r = 0; r < wh; ++r)
+            memcpy(e->h_pack + r * rb, p0 + (size_t)(y_lo + r) * s0 + (size_t)x_lo * 3, rb);
+        bytes = rb * wh;
+        f->plane0 = e->d_stage; f->stride0 = (int)rb;
+    } else {
+        const int uvw = (ww + 1) & ~1, uvh = (wh + 1) / 2;
+        for (int r = 0; r < wh; ++r)
+            memcpy(e->h_pack + (size_t)r * ww, p0 + (size_t)(y_lo + r) * s0 + x_lo, (size_t)ww);
+        const size_t uv_off = ((size_t)ww * wh + 255) & ~(size_t)255;
+        // odd frame width: the last pixel's V byte lies one past the row's last full pair
+        const int uv_avail = std::min<long>(uvw, (long)s1 - x_lo);
+        for (int r = 0; r < uvh; ++r)
+            memcpy(e->h_pack + uv_off + (size_t)r * uvw, p1 + (size_t)(y_lo / 2 + r) * s1 + x_lo, (size_t)uv_avail);
+        bytes = uv_off + (size_t)uvw * uvh;
+        f->plane0 = e->d_stage; f->plane1 = e->d_stage + uv_off; f->stride0 = ww; f->stride1 = uvw;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_stage, e->h_pack, bytes, hipMemcpyHostToDevice, e->stream));
     return VT_OK;
 }
 
@@ -869,21 +911,23 @@ static int do_update(vt_tracker* t, const vt_frame* f, vt_result* out) {
 int vt_init_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_bbox box) {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, &f)) return rc;
+    const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
+    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, fb, &f)) return rc;
     return do_init(t, &f, box);
 }
 int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_result* out) {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, &f)) return rc;
+    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
 }
 int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
                  int uv_stride, vt_bbox box) {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, &f)) return rc;
+    const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
+    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, fb, &f)) return rc;
     return do_init(t, &f, box);
 }
 int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
@@ -891,7 +935,7 @@ int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, in
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, &f)) return rc;
+    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
 }
 

@@ -134,13 +134,18 @@ int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int 
 
 typedef enum vt_pixfmt { VT_PIX_RGB8 = 0, VT_PIX_NV12 = 1 } vt_pixfmt;
 
-typedef struct vt_frame {        /* one device-resident frame */
+typedef struct vt_frame {        /* one device-resident frame (or a window of it) */
     const void* plane0;          /* RGB8: packed pixels; NV12: Y plane */
     const void* plane1;          /* NV12: interleaved UV plane; RGB8: NULL */
-    int32_t width, height;
+    int32_t width, height;       /* size of the FULL frame in pixels */
     int32_t stride0, stride1;    /* bytes */
     int32_t format;              /* vt_pixfmt */
-    int32_t reserved;
+    /* The planes may hold only a window of the frame: plane0 points at frame pixel
+     * (origin_x, origin_y) (NV12: both even; plane1 at the matching UV pair). Pixels of the frame
+     * outside the stored window must not be needed by the call (the tracker reads the search
+     * window, side 4*sqrt(w*h) around the last box, plus one pixel). 0,0 = the whole frame. */
+    int32_t origin_x, origin_y;
+    int32_t reserved;            /* 1: strides describe a window narrower than the frame */
 } vt_frame;
 
 int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out);

@@ -36,7 +36,7 @@ def test_host_library_exports_every_declared_symbol(vt):
 def test_struct_layouts_match_header(vt):
     assert ctypes.sizeof(vt.CBBox) == 16
     assert ctypes.sizeof(vt.CResult) == 24       # 24 B of result per frame
-    assert ctypes.sizeof(vt.CFrame) == 40
+    assert ctypes.sizeof(vt.CFrame) == 48
     assert ctypes.sizeof(vt.CConfig) == 24 + 32
     assert ctypes.sizeof(vt.CKernelTime) == 48 + 8 + 16
 

@@ -224,3 +224,100 @@ def test_errors_do_not_abort(gpu, weights_tiny, tmp_path):
     assert e.value.code == -6
     with pytest.raises(gpu.VtError):
         trk.init(img, gpu.BBox.new(10, 10, 0, 5))
+
+
+# ---- ingest variants, blob-from-HBM, pipelined enqueue --------------------------------------------
+
+@pytest.mark.parametrize("fmt", ["nv12", "rgb8"])
+def test_host_window_upload_equals_full_device_frame(gpu, weights_tiny, fmt):
+    """Host-pointer calls upload only the search window; the result must be identical to handing
+    the whole frame over in HBM, including windows cut by the frame border and a target that
+    leaves the frame."""
+    import torch
+    w, h = 640, 480
+    rng = np.random.default_rng(11)
+    for box in [(288, 208, 64, 64), (2, 3, 40, 50), (600, 440, 36, 36), (300, 10, 90, 30)]:
+        host, dev = gpu.VitTrack(weights_tiny), gpu.VitTrack(weights_tiny)
+        for t in range(4):
+            if fmt == "nv12":
+                buf = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+                d = torch.from_numpy(buf).cuda()
+                if t == 0:
+                    host.init(gpu.NV12Frame(buf, w, h), gpu.BBox.new(*box))
+                    dev.init_nv12_device(d.data_ptr(), d.data_ptr() + w * h, w, h, w, w,
+                                         gpu.BBox.new(*box))
+                a = host.update(gpu.NV12Frame(buf, w, h))
+                b = dev.update_nv12_device(d.data_ptr(), d.data_ptr() + w * h, w, h, w, w)
+            else:
+                img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                d = torch.from_numpy(img).cuda()
+                if t == 0:
+                    host.init(img, gpu.BBox.new(*box))
+                    dev.init_rgb8_device(d.data_ptr(), w, h, 3 * w, gpu.BBox.new(*box))
+                a = host.update(img)
+                b = dev.update_rgb8_device(d.data_ptr(), w, h, 3 * w)
+            assert a.bbox == b.bbox and a.score == b.score and a.success == b.success, (box, t)
+
+
+def test_strided_host_frames(gpu, weights_tiny):
+    """row strides larger than the width (GstVideoMeta-style padding) give the same result"""
+    import ctypes
+    w, h, pad = 640, 480, 64
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=2)
+    rgb = sc.frame_rgb8(0)
+    wide = np.zeros((h, w + pad, 3), np.uint8)
+    wide[:, :w] = rgb
+    a, b = gpu.VitTrack(weights_tiny), gpu.VitTrack(weights_tiny)
+    a.init(rgb, gpu.BBox.new(*sc.gt_box(0)))
+    ra = a.update(rgb)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L = gpu.lib()
+    box = gpu.BBox.new(*sc.gt_box(0))._c()
+    assert L.vt_init_rgb8(b._h, wide.ctypes.data_as(u8p), w, h, (w + pad) * 3, box) == 0
+    res = gpu.CResult()
+    assert L.vt_update_rgb8(b._h, wide.ctypes.data_as(u8p), w, h, (w + pad) * 3,
+                            ctypes.byref(res)) == 0
+    assert [res.bbox.x, res.bbox.y, res.bbox.width, res.bbox.height] == ra.bbox
+    assert res.score == pytest.approx(ra.score, abs=0)
+
+
+def test_create_from_device_blob(gpu, weights_tiny):
+    import torch
+    raw = np.fromfile(weights_tiny, dtype=np.uint8)
+    blob = torch.from_numpy(raw).cuda()
+    g = gpu.Group(n_streams=2, device_blob=(blob.data_ptr(), blob.numel()))
+    del blob                      # the library keeps its own copy
+    torch.cuda.empty_cache()
+    ref = gpu.Group(weights_tiny, n_streams=2)
+    w, h = 640, 480
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=6)
+    for t in range(3):
+        d = torch.from_numpy(sc.frame_nv12(t)).cuda()
+        fr = [gpu.frame_nv12(d.data_ptr(), d.data_ptr() + w * h, w, h)] * 2
+        if t == 0:
+            for grp in (g, ref):
+                for i in range(2):
+                    grp.init_device(i, fr[i], gpu.BBox.new(*sc.gt_box(0)))
+        ra, rb = g.update_device(fr), ref.update_device(fr)
+        assert [(r.bbox, r.score) for r in ra] == [(r.bbox, r.score) for r in rb]
+    assert g.model_info().weight_bytes == raw.size
+
+
+def test_pipelined_enqueue_matches_sync_updates(gpu, weights_tiny):
+    import torch
+    w, h, n = 640, 480, 24
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=8)
+    clip = [torch.from_numpy(sc.frame_nv12(t)).cuda() for t in range(n)]
+    fr = [[gpu.frame_nv12(c.data_ptr(), c.data_ptr() + w * h, w, h)] for c in clip]
+    a, b = gpu.Group(weights_tiny, n_streams=1), gpu.Group(weights_tiny, n_streams=1)
+    for grp in (a, b):
+        grp.init_device(0, fr[0][0], gpu.BBox.new(*sc.gt_box(0)))
+    for t in range(n):            # more passes in flight than descriptor-ring slots
+        a.enqueue_device(fr[t])
+    ra = a.wait()[0]
+    for t in range(n):
+        rb = b.update_device(fr[t])[0]
+    assert ra.bbox == rb.bbox and ra.score == rb.score
+    sa, sb = a.read_state(0), b.read_state(0)
+    assert sa["frames_done"] == sb["frames_done"] == n
+    assert np.array_equal(sa["box"], sb["box"])
