@@ -28,6 +28,17 @@
 #define GEMM_BK 64
 #define ROW_BYTES 128
 
+// The NS template parameter encodes the staging scheme:
+//   2..4     LDS-DMA ring of NS stages, K-tile depth 64 (128-B LDS rows)
+//   32 + d   LDS-DMA ring of d stages, K-tile depth 32 (64-B LDS rows): half the bytes per stage, so
+//            more stages in flight fit next to a second block on the CU
+//   -2       register-staged double buffer, depth 64
+__host__ __device__ constexpr int ring_depth(int ns) { return ns < 0 ? -ns : (ns >= 32 ? ns - 32 : ns); }
+__host__ __device__ constexpr int tile_bk(int ns) { return ns >= 32 ? 32 : 64; }
+__host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn) {
+    return ring_depth(ns) * (bm + bn) * tile_bk(ns) * 2;
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)gsrc,
@@ -63,15 +74,22 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE>
+template <int BM, int BN, int WVM, int WVN, int NSX, bool ROW_ON_LANE>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                               f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
+    constexpr int NS = ring_depth(NSX), BK = tile_bk(NSX);
+    constexpr int ROWB = BK * 2;                // bytes per LDS row
+    constexpr int CPR = BK / 8;                 // 16-B chunks per row (8 or 4)
+    constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB LDS-DMA piece (8 or 16)
     constexpr int NW = WVM * WVN;               // waves per block
     constexpr int WM = BM / WVM, WN = BN / WVN; // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave in each direction
-    constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);  // 1-KiB LDS-DMA pieces per wave
+    constexpr int PA = BM / (RPP * NW), PB = BN / (RPP * NW);  // 1-KiB LDS-DMA pieces per wave
     static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
-    constexpr int STAGE = (BM + BN) * ROW_BYTES;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    // chunk swizzle: 128-B rows c ^ ((r >> 1) & 7); 64-B rows c ^ ((r >> 2) & 3) — both make the
+    // ds_read_b128 of a 32-row MFMA operand hit 16 distinct 16-B slots per lane group
+    auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WVN, wc = wave % WVN;
     const int l31 = lane & 31, half = lane >> 5;
@@ -81,27 +99,27 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     const bf16_t* bsrc[PB];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
-        const int row = (wave * PA + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * PA + j) * RPP + (lane / CPR);
+        const int c = (lane % CPR) ^ swz(row);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
         asrc[j] = p.A + (size_t)gm * p.lda + c * 8;
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        const int row = (wave * PB + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * PB + j) * RPP + (lane / CPR);
+        const int c = (lane % CPR) ^ swz(row);
         bsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
     }
     auto stage = [&](int kt, int buf) {
         char* sA = smem + buf * STAGE;
-        char* sB = sA + BM * ROW_BYTES;
+        char* sB = sA + BM * ROWB;
 #pragma unroll
         for (int j = 0; j < PA; ++j)
-            glds16(asrc[j] + kt * GEMM_BK, sA + (wave * PA + j) * 8 * ROW_BYTES);
+            glds16(asrc[j] + kt * BK, sA + (wave * PA + j) * 1024);
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            glds16(bsrc[j] + kt * GEMM_BK, sB + (wave * PB + j) * 8 * ROW_BYTES);
+            glds16(bsrc[j] + kt * BK, sB + (wave * PB + j) * 1024);
     };
 
     // fragment read offsets (bytes inside a stage), per k-step the chunk index changes by 2
@@ -109,18 +127,19 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wr * WM + i * 32 + l31;
-        aoff[i] = row * ROW_BYTES;
-        aswz[i] = (row >> 1) & 7;
+        aoff[i] = row * ROWB;
+        aswz[i] = swz(row);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wc * WN + j * 32 + l31;
-        boff[j] = BM * ROW_BYTES + row * ROW_BYTES;
-        bswz[j] = (row >> 1) & 7;
+        boff[j] = BM * ROWB + row * ROWB;
+        bswz[j] = swz(row);
     }
 
     constexpr int IPS = PA + PB;  // LDS-DMA instructions per wave per stage
-    const int nk = p.K / GEMM_BK;
+    const int nk = p.K / BK;
+    constexpr int KS = BK / 16;                 // MFMA k-steps per stage
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
@@ -154,9 +173,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         for (int j = 0; j < TN; ++j)
             bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((half ^ bswz[j]) << 4));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int cb = ks & 1, nb = cb ^ 1;
-            if (ks < 3) {
+            if (ks < KS - 1) {
                 const int c = 2 * (ks + 1) + half;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -301,7 +320,7 @@ __device__ __forceinline__ void gemm_mainloop_rs(const GemmArgs& p, char* smem, 
 template <int BM, int BN, int WVM, int WVN, int NS, bool ROL>
 __device__ __forceinline__ void run_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                              f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
-    if constexpr (NS > 0) gemm_mainloop<BM, BN, WVM, WVN, NS, ROL>(p, smem, m0, n0, acc);
+    if constexpr (NS > 0) gemm_mainloop<BM, BN, WVM, WVN, NS, ROL>(p, smem, m0, n0, acc);  // NS encodes ring depth and K-tile depth
     else gemm_mainloop_rs<BM, BN, WVM, WVN, ROL>(p, smem, m0, n0, acc);
 }
 
@@ -370,9 +389,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         // assembled in LDS (the operand ring is dead by now) and written out as whole 16-B pieces
         // of contiguous rows.
         constexpr int NT = WVM * WVN * 64;
-        constexpr int NSA = NS > 0 ? NS : -NS;
-        constexpr bool FITS = BM * (BN * 2 + 16) <= NSA * (BM + BN) * ROW_BYTES &&
-                              BN * (BM * 2 + 16) <= NSA * (BM + BN) * ROW_BYTES;
+        constexpr bool FITS = BM * (BN * 2 + 16) <= ring_bytes(NS, BM, BN) &&
+                              BN * (BM * 2 + 16) <= ring_bytes(NS, BM, BN);
         bool v_tile = false;        // QKV: this column tile holds V (stored transposed)
         float scale = 1.0f;
         if constexpr (EPI == EPI_QKV) {
@@ -501,12 +519,16 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(9, 128, 128, 2, 2, -2, EPI) \
     X(10, 64, 64, 2, 2, -2, EPI)  \
     X(11, 256, 256, 2, 4, -2, EPI) \
-    X(12, 256, 128, 4, 2, -2, EPI)
-#define GEMM_NUM_CFG 13
+    X(12, 256, 128, 4, 2, -2, EPI) \
+    X(13, 256, 128, 4, 2, 35, EPI) \
+    X(14, 128, 128, 2, 2, 36, EPI) \
+    X(15, 256, 256, 2, 4, 36, EPI) \
+    X(16, 128, 256, 2, 4, 35, EPI)
+#define GEMM_NUM_CFG 17
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
-    constexpr int smem = (NS > 0 ? NS : -NS) * (BM + BN) * ROW_BYTES;
+    constexpr int smem = ring_bytes(NS, BM, BN);
     return hipFuncSetAttribute(
         reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -535,7 +557,7 @@ hipError_t gemm_prepare() {
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = (NS > 0 ? NS : -NS) * (BM + BN) * ROW_BYTES;
+    constexpr int smem = ring_bytes(NS, BM, BN);
     if (a.N % BN != 0) return hipErrorInvalidValue;
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
@@ -566,7 +588,8 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
 const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "256x256x2",
                               "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3", "128x128rs",
-                              "64x64rs", "256x256rs", "256x128rs"};
+                              "64x64rs", "256x256rs", "256x128rs", "256x128k32x3", "128x128k32x4",
+                              "256x256k32x4", "128x256k32x3"};
     return (cfg >= 0 && cfg < GEMM_NUM_CFG) ? n[cfg] : "?";
 }
 

@@ -206,6 +206,6 @@ if __name__ == "__main__":
         if nme.startswith("validate:"):
             validate(nme.split(":", 1)[1])
             continue
-        cfgs = {"tiny": (256, 500), "cfg2": (160, 400), "cfg3": (128, 400), "cfg5": (64, 300)}
+        cfgs = {"tiny": (256, 500), "cfg2": (160, 400), "cfg3": (128, 1000), "cfg5": (64, 700)}
         n, st = cfgs.get(nme, (128, 400))
         fit(nme, n, st)
