@@ -111,15 +111,15 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         const int c = (lane % CPR) ^ swz(row);
         bsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
     }
-    auto stage = [&](int kt, int buf) {
+    // piece q of a stage: q < PA -> A rows, else W rows (each piece = one global_load_lds, 1 KiB)
+    auto issue_piece = [&](int kt, int buf, int q) {
         char* sA = smem + buf * STAGE;
-        char* sB = sA + BM * ROWB;
+        if (q < PA) glds16(asrc[q] + kt * BK, sA + (wave * PA + q) * 1024);
+        else glds16(bsrc[q - PA] + kt * BK, sA + BM * ROWB + (wave * PB + (q - PA)) * 1024);
+    };
+    auto stage = [&](int kt, int buf) {
 #pragma unroll
-        for (int j = 0; j < PA; ++j)
-            glds16(asrc[j] + kt * BK, sA + (wave * PA + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            glds16(bsrc[j] + kt * BK, sB + (wave * PB + j) * 1024);
+        for (int q = 0; q < PA + PB; ++q) issue_piece(kt, buf, q);
     };
 
     // fragment read offsets (bytes inside a stage), per k-step the chunk index changes by 2
@@ -144,7 +144,14 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
     int cur = 0;
+#ifdef VT_STAMPS
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = clock64(), st_a, st_b;
+#define STAMP(v) { __builtin_amdgcn_sched_barrier(0); v = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(v)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        STAMP(st_a)
         // Tile kt must have landed; tiles kt+1 .. kt+NS-2 (those that exist) may stay in flight.
         const int ahead = min(NS - 2, nk - 1 - kt);
         if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * IPS>();
@@ -153,8 +160,19 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         // every wave's pieces of tile kt are in LDS, and every wave has finished reading the
         // stage of tile kt-1, which the next prefetch overwrites
         __builtin_amdgcn_s_barrier();
-#if !defined(VT_ABLATE) || VT_ABLATE != 1   /* 1: no operand loads after the prologue */
-        if (kt + NS - 1 < nk) stage(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+#ifdef VT_STAMPS
+        STAMP(st_b) st_wait += st_b - st_a;
+#endif
+        // The loads of the next stage are NOT issued in one burst here: one global_load_lds costs
+        // the issuing wave ~100 cycles of back-pressure from the CU's vector-memory pipeline
+        // (measured with in-kernel stamps: 8 pieces = 850 cycles, as long as the 16 MFMAs of the
+        // tile). They are spread over the k-steps below, a few after each MFMA group, so that one
+        // wave's issue stalls overlap other waves' MFMAs instead of all waves stalling together.
+        const bool prefetch = kt + NS - 1 < nk;
+        const int pf_kt = kt + NS - 1, pf_buf = cur == 0 ? NS - 1 : cur - 1;
+        (void)pf_kt; (void)pf_buf;
+#ifdef VT_STAMPS
+        STAMP(st_a) st_issue += st_a - st_b;
 #endif
         const char* sbase = smem + cur * STAGE;
 #if defined(VT_ABLATE) && VT_ABLATE == 3     /* 3: loads and barriers only */
@@ -201,9 +219,26 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
                                                                             acc[i][j], 0, 0, 0);
 #endif
                 }
+#if !defined(VT_ABLATE) || VT_ABLATE != 1   /* 1: no operand loads after the prologue */
+            if (prefetch) {
+                constexpr int Q0 = 0;  // pieces [ks*IPS/KS, (ks+1)*IPS/KS) go with k-step ks
+#pragma unroll
+                for (int q = Q0 + ks * IPS / KS; q < (ks + 1) * IPS / KS; ++q)
+                    issue_piece(pf_kt, pf_buf, q);
+            }
+#endif
         }
+#ifdef VT_STAMPS
+        STAMP(st_b) st_comp += st_b - st_a;
+#endif
         cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
+#ifdef VT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+        d[0] = st_wait; d[1] = st_issue; d[2] = st_comp; d[3] = clock64() - st_t0;
+    }
+#endif
 }
 
 // Register-staged variant of the main loop (two LDS buffers): the global loads of K-tile t+1 are

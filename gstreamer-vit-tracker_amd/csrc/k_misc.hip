@@ -105,8 +105,11 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     __shared__ float s_best[256];
     __shared__ int s_idx[256];
     __shared__ float s_logit[256][5];  // logits of each thread's own best cell
+    __shared__ float s_w4[5 * 256];    // last layer's weights (C <= 256), read by every lane
     const int b = blockIdx.x, tid = threadIdx.x;
     const int ns = a.ns, C = a.C;
+    for (int i = tid; i < 5 * C; i += 256) s_w4[i] = a.w4[i];
+    __syncthreads();
     float best = -1.0f;
     int bidx = 0x7fffffff;
     float bo[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
                 const float t = __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u)
                                                         : (w[e >> 1] << 16));
 #pragma unroll
-                for (int k = 0; k < 5; ++k) o[k] += t * a.w4[k * C + c + e];
+                for (int k = 0; k < 5; ++k) o[k] += t * s_w4[k * C + c + e];
             }
         }
         float* ho = a.head_out + ((size_t)b * ns + i) * 8;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 }
 
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
-    if (a.C % 8 != 0) return hipErrorInvalidValue;
+    if (a.C % 8 != 0 || a.C > 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -63,6 +63,7 @@ struct GemmArgs {
     bf16_t* Cb; int ldcb;         // bf16 output
     const float* pos; int pos_rows;
     bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
+    unsigned long long* dbg;      // diagnostic builds only (VT_STAMPS): per-wave cycle sums
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);

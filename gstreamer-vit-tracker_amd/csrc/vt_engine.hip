@@ -1106,6 +1106,13 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     g.qk = (bf16_t*)dcb.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
     if (epilogue == EPI_QKV && (N % 192 || tokens != M)) return set_err(VT_ERR_INVALID_ARG, "qkv bench: N = 3D, D % 64 == 0, M % 4 == 0");
     if (cfg < 0) cfg = gemm_pick_config(M, N, K, epilogue);
+    DevBuf ddbg;
+    const size_t dbg_words = (size_t)((M + 63) / 64) * (N / 64) * 8 * 4;
+    if (getenv("VT_STAMPS_DUMP")) {
+        HIPCHK(ddbg.alloc(dbg_words * 8));
+        HIPCHK(hipMemset(ddbg.p, 0, dbg_words * 8));
+        g.dbg = (unsigned long long*)ddbg.p;
+    }
     for (int i = 0; i < 3; ++i) HIPCHK(launch_gemm_cfg(g, epilogue, cfg, nullptr));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1117,6 +1124,16 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *us_out = ms * 1000.0f / iters;
+    if (g.dbg) {   // diagnostic build: mean per-wave cycle split of the main loop
+        std::vector<unsigned long long> h(dbg_words);
+        HIPCHK(hipMemcpy(h.data(), ddbg.p, dbg_words * 8, hipMemcpyDeviceToHost));
+        double s[4] = {0, 0, 0, 0};
+        size_t n = 0;
+        for (size_t i = 0; i + 3 < dbg_words; i += 4)
+            if (h[i + 3]) { for (int k = 0; k < 4; ++k) s[k] += (double)h[i + k]; ++n; }
+        if (n) fprintf(stderr, "stamps cfg %d: waves %zu  wait %.0f  issue %.0f  compute %.0f  loop total %.0f cycles/wave\n",
+                       cfg, n, s[0] / n, s[1] / n, s[2] / n, s[3] / n);
+    }
     return VT_OK;
 }
 

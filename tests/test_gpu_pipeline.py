@@ -171,6 +171,15 @@ def test_trajectory_cfg3_nv12_1080p(gpu, oracle, weights_cfg3):
     _assert_parity(sc, bg, br, s)
 
 
+def test_trajectory_cfg5_vitl14_4k(gpu, oracle):
+    """BASELINE.json configs[4]: 4K NV12, ViT-L/14 template196/search392 (980 tokens, patch 14 ->
+    K padded 588 -> 640, tokens % 8 != 0, 24 layers). Short clip: the oracle needs seconds per frame."""
+    weights = gpu.weights.ensure_weights("cfg5")
+    sc = gpu.synth.MovingSquare(3840, 2160, 160, seed=3)
+    bg, br, s = _run_pair(gpu, oracle, weights, sc, 10)
+    _assert_parity(sc, bg, br, s)
+
+
 def test_graph_and_eager_agree(gpu, weights_tiny):
     sc = gpu.synth.MovingSquare(640, 480, 64, seed=4)
     out = []
