@@ -96,7 +96,39 @@ hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C
     return hipGetLastError();
 }
 
-// ---- last head layer (C -> 5 logits, f32) + score window + argmax + box decode --------------------
+// ---- last head layer (C -> 5 logits, f32): one wave per search token -----------------------------
+// lanes stride over the channels, five dot products, wave reduction. Kept apart from the decode so
+// that it runs token-parallel over the whole chip (as one block per stream it was a 40 us serial
+// tail of every frame).
+__global__ __launch_bounds__(256) void head_out_kernel(const bf16_t* __restrict__ t3,
+                                                       const float* __restrict__ w4,
+                                                       const float* __restrict__ b4,
+                                                       float* __restrict__ head_out, int rows,
+                                                       int C) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* row = t3 + (size_t)r * C;
+    float o[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = lane * 2; c < C; c += 128) {
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(row + c);
+        const float t0 = __uint_as_float(pk << 16), t1 = __uint_as_float(pk & 0xffff0000u);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] += t0 * w4[k * C + c] + t1 * w4[k * C + c + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) o[k] += __shfl_xor(o[k], off);
+    if (lane == 0) {
+        float* ho = head_out + (size_t)r * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ho[k] = o[k] + b4[k];
+        ho[5] = ho[6] = ho[7] = 0.0f;
+    }
+}
+
+// ---- score window + argmax + box decode -------------------------------------------------------------
 // One 256-thread block per stream. Writes vt_result and the stream state the next frame's
 // preprocessing reads. Same float op order as vto_decode (oracle/vt_oracle.c).
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -105,34 +137,16 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     __shared__ float s_best[256];
     __shared__ int s_idx[256];
     __shared__ float s_logit[256][5];  // logits of each thread's own best cell
-    __shared__ float s_w4[5 * 256];    // last layer's weights (C <= 256), read by every lane
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int ns = a.ns, C = a.C;
-    for (int i = tid; i < 5 * C; i += 256) s_w4[i] = a.w4[i];
-    __syncthreads();
+    const int ns = a.ns;
     float best = -1.0f;
     int bidx = 0x7fffffff;
     float bo[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = tid; i < ns; i += 256) {
-        const bf16_t* row = a.t3 + ((size_t)b * ns + i) * C;
+        const float* ho = a.head_out + ((size_t)b * ns + i) * 8;
         float o[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) o[k] = 0.0f;
-        for (int c = 0; c < C; c += 8) {
-            const uint4 pk = *reinterpret_cast<const uint4*>(row + c);
-            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u)
-                                                        : (w[e >> 1] << 16));
-#pragma unroll
-                for (int k = 0; k < 5; ++k) o[k] += t * s_w4[k * C + c + e];
-            }
-        }
-        float* ho = a.head_out + ((size_t)b * ns + i) * 8;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { o[k] += a.b4[k]; ho[k] = o[k]; }
-        ho[5] = ho[6] = ho[7] = 0.0f;
+        for (int k = 0; k < 5; ++k) o[k] = ho[k];
         const float resp = sigmoidf_(o[0]) * a.hann[i];
         if (resp > best) {  // ascending i per thread: first max kept
             best = resp; bidx = i;
@@ -162,8 +176,8 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const float score = sigmoidf_(s_logit[idx & 255][0]);  // cell i is handled by thread i % 256
     const int grid = a.grid;
     const int bx = idx % grid, by = idx / grid;
-    // response^2-weighted mean over the 3x3 window around the argmax (see vto_decode). The other
-    // threads' head_out rows were written before the barriers above (same workgroup, same CU).
+    // response^2-weighted mean over the 3x3 window around the argmax (see vto_decode); head_out was
+    // written by the preceding head_out_kernel launch.
     float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
     for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
@@ -217,7 +231,10 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 }
 
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
-    if (a.C % 8 != 0 || a.C > 256) return hipErrorInvalidValue;
+    if (a.C % 2 != 0) return hipErrorInvalidValue;
+    const int rows = a.B * a.ns;
+    hipLaunchKernelGGL(head_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a.t3, a.w4, a.b4, a.head_out,
+                       rows, a.C);
     hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
