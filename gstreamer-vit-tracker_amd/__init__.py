@@ -21,7 +21,7 @@ from . import synth    # noqa: F401
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITTRACK_HIP_LIB", os.path.join(PKG_DIR, "libvittrack_hip.so"))
 
-PIX_RGB8, PIX_NV12 = 0, 1
+PIX_RGB8, PIX_NV12, PIX_YUY2 = 0, 1, 2
 
 
 class VtError(RuntimeError):
@@ -71,7 +71,7 @@ _lib = None
 EXPORTS = [
     "vt_config_default", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_create",
     "vt_create_from_device_blob", "vt_destroy", "vt_get_model_info", "vt_init_rgb8",
-    "vt_update_rgb8", "vt_init_nv12", "vt_update_nv12", "vt_init_rgb8_device",
+    "vt_update_rgb8", "vt_init_yuy2", "vt_update_yuy2", "vt_init_nv12", "vt_update_nv12", "vt_init_rgb8_device",
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
@@ -109,6 +109,8 @@ def lib():
     u8p = POINTER(c_uint8)
     L.vt_init_rgb8.argtypes = [c_void_p, u8p, c_int, c_int, c_int, CBBox]
     L.vt_update_rgb8.argtypes = [c_void_p, u8p, c_int, c_int, c_int, POINTER(CResult)]
+    L.vt_init_yuy2.argtypes = [c_void_p, u8p, c_int, c_int, c_int, CBBox]
+    L.vt_update_yuy2.argtypes = [c_void_p, u8p, c_int, c_int, c_int, POINTER(CResult)]
     L.vt_init_nv12.argtypes = [c_void_p, u8p, u8p, c_int, c_int, c_int, c_int, CBBox]
     L.vt_update_nv12.argtypes = [c_void_p, u8p, u8p, c_int, c_int, c_int, c_int, POINTER(CResult)]
     L.vt_init_rgb8_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, CBBox]
@@ -236,6 +238,15 @@ class NV12Frame:
         assert self.buf.size >= width * height + ((width + 1) & ~1) * ((height + 1) // 2)
 
 
+class YUY2Frame:
+    """packed 4:2:2 host frame (Y0 U Y1 V), rows of 2*width bytes (src/pipeline_ir.rs:27-41)"""
+
+    def __init__(self, buf: np.ndarray, width: int, height: int):
+        self.buf = np.ascontiguousarray(buf, np.uint8).reshape(-1)
+        self.w, self.h = width, height
+        assert self.buf.size >= 2 * width * height and width % 2 == 0
+
+
 class VitTrack:
     """≙ vit_tracker::VitTrack (src/tracker_context.rs:21,88,90,120)."""
 
@@ -267,7 +278,10 @@ class VitTrack:
     def init(self, frame, bbox: BBox) -> None:
         """frame: (H,W,3) uint8 RGB array (≙ ArrayView3<u8>) or NV12Frame. Like the reference's
         call site (src/tracker_context.rs:88) the caller gets nothing back; errors raise."""
-        if isinstance(frame, NV12Frame):
+        if isinstance(frame, YUY2Frame):
+            _check(lib().vt_init_yuy2(self._h, _u8(frame.buf), frame.w, frame.h, 2 * frame.w,
+                                      bbox._c()))
+        elif isinstance(frame, NV12Frame):
             y = frame.buf
             uv = frame.buf[frame.w * frame.h:]
             _check(lib().vt_init_nv12(self._h, _u8(y), _u8(uv), frame.w, frame.h, frame.w,
@@ -279,7 +293,10 @@ class VitTrack:
 
     def update(self, frame) -> TrackResult:
         r = CResult()
-        if isinstance(frame, NV12Frame):
+        if isinstance(frame, YUY2Frame):
+            _check(lib().vt_update_yuy2(self._h, _u8(frame.buf), frame.w, frame.h, 2 * frame.w,
+                                        byref(r)))
+        elif isinstance(frame, NV12Frame):
             y = frame.buf
             uv = frame.buf[frame.w * frame.h:]
             _check(lib().vt_update_nv12(self._h, _u8(y), _u8(uv), frame.w, frame.h, frame.w,

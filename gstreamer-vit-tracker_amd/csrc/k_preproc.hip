@@ -90,10 +90,13 @@ __device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, fl
     if (f.fmt == VT_PIX_RGB8) {
         const uint8_t* p = f.p0 + (size_t)sy * f.s0 + (size_t)sx * 3;
         r = p[0]; g = p[1]; b = p[2];
-    } else {
+    } else if (f.fmt == VT_PIX_NV12) {
         const int y = f.p0[(size_t)sy * f.s0 + sx];
         const uint8_t* uv = f.p1 + (size_t)(sy >> 1) * f.s1 + (sx & ~1);   // x0, y0 even
         yuv_to_rgb(y, uv[0], uv[1], r, g, b);
+    } else {  // YUY2: Y0 U Y1 V per pixel pair
+        const uint8_t* p = f.p0 + (size_t)sy * f.s0 + (size_t)(sx & ~1) * 2;
+        yuv_to_rgb(p[(sx & 1) * 2], p[1], p[3], r, g, b);
     }
     rgb[0] = (float)r; rgb[1] = (float)g; rgb[2] = (float)b;
 }

@@ -473,11 +473,15 @@ static int check_frame(const vt_frame& f) {
     } else if (f.format == VT_PIX_NV12) {
         if (!f.plane1 || f.stride0 < (window ? 2 : f.width) || f.stride1 < (window ? 2 : ((f.width + 1) & ~1)))
             return set_err(VT_ERR_INVALID_ARG, "nv12: null UV plane or stride too small");
+    } else if (f.format == VT_PIX_YUY2) {
+        if ((f.width & 1) || f.stride0 < (window ? 4 : f.width * 2))
+            return set_err(VT_ERR_INVALID_ARG, "yuy2: odd width or stride < 2*width");
     } else {
         return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", f.format);
     }
     if (f.origin_x < 0 || f.origin_y < 0 || f.origin_x >= f.width || f.origin_y >= f.height ||
-        (f.format == VT_PIX_NV12 && ((f.origin_x | f.origin_y) & 1)))
+        (f.format == VT_PIX_NV12 && ((f.origin_x | f.origin_y) & 1)) ||
+        (f.format == VT_PIX_YUY2 && (f.origin_x & 1)))
         return set_err(VT_ERR_INVALID_ARG, "frame window origin %d,%d invalid", f.origin_x, f.origin_y);
     return VT_OK;
 }
@@ -850,6 +854,8 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
         return set_err(VT_ERR_INVALID_ARG, "frame %dx%d exceeds configured max %dx%d", w, h, e->max_w, e->max_h);
     if (fmt == VT_PIX_RGB8) {
         if (s0 < 3 * w) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
+    } else if (fmt == VT_PIX_YUY2) {
+        if ((w & 1) || s0 < 2 * w) return set_err(VT_ERR_INVALID_ARG, "yuy2: odd width or stride < 2*width");
     } else if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) {
         return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
     }
@@ -878,10 +884,11 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
     f->origin_x = (int)x_lo; f->origin_y = (int)y_lo;
     f->reserved = 1;   // strides describe the packed window
     size_t bytes;
-    if (fmt == VT_PIX_RGB8) {
-        const size_t rb = (size_t)ww * 3;
+    if (fmt == VT_PIX_RGB8 || fmt == VT_PIX_YUY2) {
+        const size_t bpp = fmt == VT_PIX_RGB8 ? 3 : 2;
+        const size_t rb = (size_t)ww * bpp;
         for (int r = 0; r < wh; ++r)
-            memcpy(e->h_pack + r * rb, p0 + (size_t)(y_lo + r) * s0 + (size_t)x_lo * 3, rb);
+            memcpy(e->h_pack + r * rb, p0 + (size_t)(y_lo + r) * s0 + (size_t)x_lo * bpp, rb);
         bytes = rb * wh;
         f->plane0 = e->d_stage; f->stride0 = (int)rb;
     } else {
@@ -920,6 +927,20 @@ int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_b
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
     if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
+    return do_update(t, &f, out);
+}
+int vt_init_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_bbox box) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    vt_frame f;
+    const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
+    if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, fb, &f)) return rc;
+    return do_init(t, &f, box);
+}
+int vt_update_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_result* out) {
+    if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
+    if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
+    vt_frame f;
+    if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
 }
 int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,

@@ -120,6 +120,12 @@ int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int 
 int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h,
                    int y_stride, int uv_stride, vt_result* out);
 
+/* Fused YUY2 ingest (packed 4:2:2, stride in bytes >= 2*w, w even): the capture format of the
+ * reference's live pipeline (src/pipeline_ir.rs:27-41), so the host can skip videoconvert. */
+int vt_init_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_bbox box);
+int vt_update_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes,
+                   vt_result* out);
+
 /* Same four calls with the frame already resident in this GPU's HBM (device pointers). */
 int vt_init_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes,
                         vt_bbox box);
@@ -132,7 +138,10 @@ int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int 
 
 /* ---- B streams on one GPU (one stream per camera; no cross-stream data flow) ------------ */
 
-typedef enum vt_pixfmt { VT_PIX_RGB8 = 0, VT_PIX_NV12 = 1 } vt_pixfmt;
+/* VT_PIX_YUY2: packed 4:2:2, bytes Y0 U Y1 V per pixel pair (the format the reference's IR
+ * pipeline captures, src/pipeline_ir.rs:27-41, before GStreamer's videoconvert turns it into RGB);
+ * converted per sampled pixel with the same BT.601 integer formulas as NV12. */
+typedef enum vt_pixfmt { VT_PIX_RGB8 = 0, VT_PIX_NV12 = 1, VT_PIX_YUY2 = 2 } vt_pixfmt;
 
 typedef struct vt_frame {        /* one device-resident frame (or a window of it) */
     const void* plane0;          /* RGB8: packed pixels; NV12: Y plane */

@@ -20,9 +20,11 @@ LIB = os.path.join(HERE, "libvt_oracle.so")
 def build(force: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
         return LIB
+    tmp = LIB + f".tmp{os.getpid()}"
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
-           "-fopenmp", "-o", LIB, SRC, "-lm"]
+           "-fopenmp", "-o", tmp, SRC, "-lm"]
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)   # new inode: a process that has the old library mapped keeps it intact
     return LIB
 
 

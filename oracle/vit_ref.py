@@ -107,6 +107,12 @@ class Frame:
         return Frame(0, arr, None, w, h, w * 3, 0)
 
     @staticmethod
+    def yuy2(arr, w, h):
+        """packed 4:2:2 (Y0 U Y1 V), rows of 2*w bytes"""
+        arr = np.ascontiguousarray(arr, np.uint8).reshape(-1)
+        return Frame(2, arr, None, w, h, 2 * w, 0)
+
+    @staticmethod
     def nv12(buf, w, h):
         """packed NV12 buffer, stride == width (src/nv12_convert.rs:53-54)"""
         buf = np.ascontiguousarray(buf, np.uint8).reshape(-1)

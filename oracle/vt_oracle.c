@@ -181,7 +181,7 @@ void vto_crop_geometry(const float* box, float factor, int out_size, float* geo)
 typedef struct {
     const uint8_t* p0; /* RGB8 packed or Y plane */
     const uint8_t* p1; /* UV plane (NV12) */
-    int w, h, s0, s1, fmt; /* fmt 0 = RGB8, 1 = NV12 */
+    int w, h, s0, s1, fmt; /* fmt 0 = RGB8, 1 = NV12, 2 = YUY2 */
 } vto_frame;
 
 /* pixel (px,py) of the frame as RGB; outside the frame -> (0,0,0) */
@@ -194,12 +194,17 @@ static inline void fetch_rgb(const vto_frame* f, int px, int py, float* rgb) {
     if (f->fmt == 0) {
         const uint8_t* p = f->p0 + (size_t)py * f->s0 + (size_t)px * 3;
         c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
-    } else {
+    } else if (f->fmt == 1) {
         /* same addressing as src/nv12_convert.rs:111-113,152: UV pair of column (px & ~1),
          * UV row py/2 */
         uint8_t yy = f->p0[(size_t)py * f->s0 + px];
         const uint8_t* uvp = f->p1 + (size_t)(py >> 1) * f->s1 + (px & ~1);
         vto_yuv_to_rgb_px(yy, uvp[0], uvp[1], c);
+    } else {
+        /* YUY2 (capture format of src/pipeline_ir.rs:27-41): Y0 U Y1 V per pixel pair, same
+         * integer conversion */
+        const uint8_t* p = f->p0 + (size_t)py * f->s0 + (size_t)(px & ~1) * 2;
+        vto_yuv_to_rgb_px(p[(px & 1) * 2], p[1], p[3], c);
     }
     rgb[0] = (float)c[0]; rgb[1] = (float)c[1]; rgb[2] = (float)c[2];
 }

@@ -68,6 +68,17 @@ def test_patch_matrix_bit_exact_nv12(gpu, oracle, weights_tiny, box):
     assert np.array_equal(got, want)
 
 
+def test_patch_matrix_bit_exact_yuy2(gpu, oracle, weights_tiny):
+    """the IR pipeline's capture format (src/pipeline_ir.rs:27-41), 640x512"""
+    rng = np.random.default_rng(9)
+    w, h = 640, 512
+    buf = rng.integers(0, 256, 2 * w * h, dtype=np.uint8)
+    got, want, r_gpu, r_ref = _patches_case(gpu, oracle, weights_tiny, gpu.YUY2Frame(buf, w, h),
+                                            oracle.Frame.yuy2(buf, w, h), (301, 203, 70, 50))
+    assert np.array_equal(got, want)
+    assert max(abs(a - b) for a, b in zip(r_gpu.bbox, r_ref.bbox)) <= 1
+
+
 def test_patch_matrix_bit_exact_rgb8(gpu, oracle, weights_tiny):
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
