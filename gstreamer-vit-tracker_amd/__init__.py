@@ -60,6 +60,14 @@ class CFrame(Structure):
                 ("reserved", c_int32)]
 
 
+class CDrawCmd(Structure):
+    _fields_ = [("type", c_int32), ("x", c_int32), ("y", c_int32), ("w", c_int32), ("h", c_int32),
+                ("p", c_int32), ("value", c_int32), ("text", c_char * 36)]
+
+
+DRAW_BACKGROUND, DRAW_TEXT, DRAW_RECT, DRAW_CROSSHAIR, DRAW_CURSOR, DRAW_SELECTION = range(6)
+
+
 class CKernelTime(Structure):
     _fields_ = [("name", c_char * 48), ("launches", c_int32), ("ms_total", c_float),
                 ("flops", c_double), ("bytes", c_double)]
@@ -75,7 +83,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device",
+    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_attention_bench", "vt_op_layernorm",
@@ -142,6 +150,9 @@ def lib():
     L.vt_nv12_to_rgb8.argtypes = [c_int, u8p, c_size_t, c_int, c_int, u8p]
     L.vt_nv12_to_rgb8_device.argtypes = [c_int, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                          c_void_p]
+    L.vt_overlay_nv12_device.argtypes = [c_int, c_void_p, c_int, c_int, c_int, POINTER(CDrawCmd), c_int,
+                                         c_void_p]
+    L.vt_overlay_nv12.argtypes = [c_int, u8p, c_int, c_int, POINTER(CDrawCmd), c_int]
     u16p, fp = POINTER(c_uint16), POINTER(c_float)
     L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int]
     L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
@@ -437,6 +448,20 @@ def nv12_full_to_rgb(nv12_data: np.ndarray, width: int, height: int, device: int
     out = np.empty((height, width, 3), np.uint8)
     _check(lib().vt_nv12_to_rgb8(device, _u8(buf), buf.size, width, height, _u8(out)))
     return out
+
+
+# ---- overlays (the reference's per-frame drawing, on the GPU) -------------------------------------
+
+def draw_cmd(kind, x=0, y=0, w=0, h=0, p=0, value=0, text="") -> CDrawCmd:
+    return CDrawCmd(kind, x, y, w, h, p, value, text.encode()[:35])
+
+
+def overlay_nv12(nv12: np.ndarray, width: int, height: int, cmds, device: int = 0) -> np.ndarray:
+    """apply draw commands to the luma plane of a packed NV12 host buffer (returns a copy)"""
+    buf = np.ascontiguousarray(nv12, np.uint8).reshape(-1).copy()
+    arr = (CDrawCmd * len(cmds))(*cmds)
+    _check(lib().vt_overlay_nv12(device, _u8(buf), width, height, arr, len(cmds)))
+    return buf
 
 
 # ---- operator-level entry points (numerics tests) -------------------------------------------

@@ -23,7 +23,8 @@ LIB_HIP = os.path.join(PKG, "libvittrack_hip.so")
 LIB_HOST = os.path.join(PKG, "libvittrack_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "vt_engine.hip"]
+HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "k_overlay.hip",
+               "vt_engine.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",
              "-Wno-unused-function"]

@@ -1049,13 +1049,48 @@ int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h
     return rc;
 }
 
-// ---- operator-level entry points ---------------------------------------------------------------------------
-
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
 };
+
+// ---- overlays ---------------------------------------------------------------------------------------------
+
+int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int stride, const vt_draw_cmd* cmds,
+                           int n, void* hip_stream) {
+    if (!d_y || width <= 0 || height <= 0 || stride < width || n < 0 || (n > 0 && !cmds))
+        return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (n == 0) return VT_OK;
+    if (n > 256) return set_err(VT_ERR_INVALID_ARG, "at most 256 draw commands per call");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    hipStream_t st = (hipStream_t)hip_stream;
+    vt_draw_cmd* d_cmds = nullptr;
+    HIPCHK(hipMallocAsync((void**)&d_cmds, sizeof(vt_draw_cmd) * n, st));
+    hipError_t e = hipMemcpyAsync(d_cmds, cmds, sizeof(vt_draw_cmd) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_overlay((uint8_t*)d_y, width, height, stride, d_cmds, n, st);
+    (void)hipFreeAsync(d_cmds, st);
+    if (e != hipSuccess) return set_err(VT_ERR_HIP, "overlay: %s", hipGetErrorString(e));
+    // pageable source: hipMemcpyAsync has consumed `cmds` when it returns
+    return VT_OK;
+}
+
+int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds, int n) {
+    if (!nv12 || width <= 0 || height <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    DevBuf dy;
+    const size_t bytes = (size_t)width * height;
+    HIPCHK(dy.alloc(bytes));
+    HIPCHK(hipMemcpy(dy.p, nv12, bytes, hipMemcpyHostToDevice));
+    if (int rc = vt_overlay_nv12_device(device_id, dy.p, width, height, width, cmds, n, nullptr)) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(nv12, dy.p, bytes, hipMemcpyDeviceToHost));
+    return VT_OK;
+}
+
+// ---- operator-level entry points ---------------------------------------------------------------------------
 
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* c_inout,
                     int M, int N, int K, int epilogue) {

@@ -187,6 +187,36 @@ int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h
 int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w, int h,
                            void* d_rgb_out, void* hip_stream);
 
+/* ---- overlay drawing on the GPU (the reference's per-frame overlays) --------------------------- */
+
+/* ≙ draw_background_nv12 / draw_text_nv12 / draw_rect_nv12 / draw_crosshair_nv12
+ * (src/nv12_convert.rs:172-343) and draw_cursor / draw_selection (src/drawing.rs:5-50), applied in
+ * list order to the luma plane of an NV12 frame, bit-exact with the reference's CPU loops. */
+typedef enum vt_draw_type {
+    VT_DRAW_BACKGROUND = 0, /* x, y, w, h; value = darkness                                */
+    VT_DRAW_TEXT = 1,       /* x, y; p = scale; value = brightness; text (5x7 font, 40 glyphs) */
+    VT_DRAW_RECT = 2,       /* x, y, w, h; p = thickness; value = brightness                */
+    VT_DRAW_CROSSHAIR = 3,  /* x, y = centre; p = size; value = brightness                  */
+    VT_DRAW_CURSOR = 4,     /* x, y                                                         */
+    VT_DRAW_SELECTION = 5   /* x, y = start corner; w, h = cursor corner (dashed frame)     */
+} vt_draw_type;
+
+typedef struct vt_draw_cmd {
+    int32_t type;           /* vt_draw_type */
+    int32_t x, y, w, h;
+    int32_t p;
+    int32_t value;
+    char text[36];          /* NUL-terminated, VT_DRAW_TEXT only */
+} vt_draw_cmd;
+
+/* Apply n commands to a device-resident luma plane (width x height, `stride` bytes per row),
+ * enqueued on hip_stream (NULL = default stream); the command list is copied before returning. */
+int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int stride,
+                           const vt_draw_cmd* cmds, int n, void* hip_stream);
+/* Host-pointer form: draws into the packed NV12 buffer (stride == width) in place. */
+int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds,
+                    int n);
+
 /* ---- per-kernel timing and stage taps (parity tests, bench roofline) -------------------- */
 
 typedef struct vt_kernel_time {

@@ -45,6 +45,13 @@ def lib():
         _lib.vto_preproc.argtypes = [c_u8p, c_u8p] + [ctypes.c_int] * 5 + [
             c_fp, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp,
             ctypes.POINTER(ctypes.c_uint16)]
+        sz, i32, u8 = ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint8
+        _lib.vto_draw_rect_nv12.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32, sz, u8]
+        _lib.vto_draw_crosshair_nv12.argtypes = [c_u8p, sz, sz, i32, i32, i32, u8]
+        _lib.vto_draw_text_nv12.argtypes = [c_u8p, sz, sz, ctypes.c_char_p, sz, sz, sz, u8]
+        _lib.vto_draw_background_nv12.argtypes = [c_u8p, sz, sz, sz, sz, sz, sz, u8]
+        _lib.vto_draw_cursor.argtypes = [c_u8p, sz, sz, i32, i32]
+        _lib.vto_draw_selection.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32]
         _lib.vto_decode.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
                                     c_fp, ctypes.POINTER(ctypes.c_int32)]
     return _lib
@@ -90,6 +97,29 @@ def yuv_px(y, u, v):
     o = np.zeros(3, np.uint8)
     lib().vto_yuv_to_rgb_px(int(y), int(u), int(v), _u8p(o))
     return tuple(int(x) for x in o)
+
+
+# ---- overlay drawing (reference stage: src/nv12_convert.rs:172-343, src/drawing.rs:5-50) ----------
+
+def draw(nv12: np.ndarray, w: int, h: int, cmds) -> np.ndarray:
+    """apply (kind, x, y, w, h, p, value, text) commands in order with the line-by-line C
+    restatements; kinds: 0 background, 1 text, 2 rect, 3 crosshair, 4 cursor, 5 selection"""
+    buf = np.ascontiguousarray(nv12, np.uint8).reshape(-1).copy()
+    L, p = lib(), _u8p(buf)
+    for (kind, x, y, cw, ch, pp, value, text) in cmds:
+        if kind == 0:
+            L.vto_draw_background_nv12(p, w, h, x, y, cw, ch, value)
+        elif kind == 1:
+            L.vto_draw_text_nv12(p, w, h, text.encode(), x, y, pp, value)
+        elif kind == 2:
+            L.vto_draw_rect_nv12(p, w, h, x, y, cw, ch, pp, value)
+        elif kind == 3:
+            L.vto_draw_crosshair_nv12(p, w, h, x, y, pp, value)
+        elif kind == 4:
+            L.vto_draw_cursor(p, w, h, x, y)
+        elif kind == 5:
+            L.vto_draw_selection(p, w, h, x, y, cw, ch)
+    return buf
 
 
 # ---- frames ---------------------------------------------------------------------------------

@@ -314,3 +314,130 @@ void vto_decode(const float* head_out, const float* hann, int grid, const float*
     ibox[2] = (int32_t)floorf(bw + 0.5f);
     ibox[3] = (int32_t)floorf(bh + 0.5f);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Overlay drawing on the NV12 Y plane   (reference: src/nv12_convert.rs:172-343, src/drawing.rs:5-50)
+ * Line-by-line restatements; `usize` arithmetic is restated with size_t so that the reference's
+ * wrap-around quirks (a negative i32 cast to usize) are preserved.
+ * ------------------------------------------------------------------------------------------- */
+
+static inline size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
+static inline size_t sat_sub(size_t a, size_t b) { return a > b ? a - b : 0; }
+
+/* src/nv12_convert.rs:172-213 */
+void vto_draw_rect_nv12(uint8_t* nv12, size_t width, size_t height, int32_t x, int32_t y, int32_t w,
+                        int32_t h, size_t thickness, uint8_t brightness) {
+    size_t x1 = (size_t)(x > 0 ? x : 0), y1 = (size_t)(y > 0 ? y : 0);
+    size_t x2 = zmin((size_t)(int64_t)(x + w), sat_sub(width, 1));   /* (x + w) as usize wraps */
+    size_t y2 = zmin((size_t)(int64_t)(y + h), sat_sub(height, 1));
+    uint8_t* yp = nv12;
+    for (size_t t = 0; t < thickness; ++t) {
+        if (y1 + t < height)
+            for (size_t px = x1; px <= x2; ++px) yp[(y1 + t) * width + px] = brightness;
+        if (y2 >= t && y2 - t < height)
+            for (size_t px = x1; px <= x2; ++px) yp[(y2 - t) * width + px] = brightness;
+    }
+    for (size_t py = y1; py <= y2; ++py)
+        for (size_t t = 0; t < thickness; ++t) {
+            if (x1 + t < width) yp[py * width + x1 + t] = brightness;
+            if (x2 >= t && x2 - t < width) yp[py * width + x2 - t] = brightness;
+        }
+}
+
+/* src/nv12_convert.rs:216-243 */
+void vto_draw_crosshair_nv12(uint8_t* nv12, size_t width, size_t height, int32_t cx_, int32_t cy_,
+                             int32_t size_, uint8_t brightness) {
+    size_t cx = (size_t)(cx_ > 0 ? cx_ : 0), cy = (size_t)(cy_ > 0 ? cy_ : 0);
+    size_t size = (size_t)(int64_t)size_;
+    if (cy < height)
+        for (size_t xx = sat_sub(cx, size); xx <= zmin(cx + size, width - 1); ++xx)
+            nv12[cy * width + xx] = brightness;
+    if (cx < width)
+        for (size_t yy = sat_sub(cy, size); yy <= zmin(cy + size, height - 1); ++yy)
+            nv12[yy * width + cx] = brightness;
+}
+
+/* the 5x7 font of src/nv12_convert.rs:257-298 (40 glyphs) */
+static const struct { char c; uint8_t rows[7]; } kFont[] = {
+    {'0', {0x0E, 0x11, 0x13, 0x15, 0x19, 0x11, 0x0E}}, {'1', {0x04, 0x0C, 0x04, 0x04, 0x04, 0x04, 0x0E}},
+    {'2', {0x0E, 0x11, 0x01, 0x06, 0x08, 0x10, 0x1F}}, {'3', {0x0E, 0x11, 0x01, 0x06, 0x01, 0x11, 0x0E}},
+    {'4', {0x02, 0x06, 0x0A, 0x12, 0x1F, 0x02, 0x02}}, {'5', {0x1F, 0x10, 0x1E, 0x01, 0x01, 0x11, 0x0E}},
+    {'6', {0x06, 0x08, 0x10, 0x1E, 0x11, 0x11, 0x0E}}, {'7', {0x1F, 0x01, 0x02, 0x04, 0x08, 0x08, 0x08}},
+    {'8', {0x0E, 0x11, 0x11, 0x0E, 0x11, 0x11, 0x0E}}, {'9', {0x0E, 0x11, 0x11, 0x0F, 0x01, 0x02, 0x0C}},
+    {'.', {0x00, 0x00, 0x00, 0x00, 0x00, 0x0C, 0x0C}}, {':', {0x00, 0x0C, 0x0C, 0x00, 0x0C, 0x0C, 0x00}},
+    {'-', {0x00, 0x00, 0x00, 0x1F, 0x00, 0x00, 0x00}}, {' ', {0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00}},
+    {'F', {0x1F, 0x10, 0x1E, 0x10, 0x10, 0x10, 0x10}}, {'P', {0x1E, 0x11, 0x1E, 0x10, 0x10, 0x10, 0x10}},
+    {'S', {0x0E, 0x11, 0x10, 0x0E, 0x01, 0x11, 0x0E}}, {'T', {0x1F, 0x04, 0x04, 0x04, 0x04, 0x04, 0x04}},
+    {'R', {0x1E, 0x11, 0x1E, 0x14, 0x12, 0x11, 0x11}}, {'A', {0x0E, 0x11, 0x1F, 0x11, 0x11, 0x11, 0x11}},
+    {'C', {0x0E, 0x11, 0x10, 0x10, 0x10, 0x11, 0x0E}}, {'K', {0x11, 0x12, 0x14, 0x18, 0x14, 0x12, 0x11}},
+    {'I', {0x0E, 0x04, 0x04, 0x04, 0x04, 0x04, 0x0E}}, {'N', {0x11, 0x19, 0x15, 0x13, 0x11, 0x11, 0x11}},
+    {'G', {0x0E, 0x11, 0x10, 0x17, 0x11, 0x11, 0x0E}}, {'E', {0x1F, 0x10, 0x1E, 0x10, 0x10, 0x10, 0x1F}},
+    {'L', {0x10, 0x10, 0x10, 0x10, 0x10, 0x10, 0x1F}}, {'O', {0x0E, 0x11, 0x11, 0x11, 0x11, 0x11, 0x0E}},
+    {'D', {0x1C, 0x12, 0x11, 0x11, 0x11, 0x12, 0x1C}}, {'%', {0x19, 0x1A, 0x04, 0x04, 0x08, 0x0B, 0x13}},
+    {'s', {0x00, 0x00, 0x0E, 0x10, 0x0E, 0x01, 0x1E}}, {'c', {0x00, 0x00, 0x0E, 0x10, 0x10, 0x11, 0x0E}},
+    {'o', {0x00, 0x00, 0x0E, 0x11, 0x11, 0x11, 0x0E}}, {'r', {0x00, 0x00, 0x16, 0x19, 0x10, 0x10, 0x10}},
+    {'e', {0x00, 0x00, 0x0E, 0x11, 0x1F, 0x10, 0x0E}}, {'m', {0x00, 0x00, 0x1A, 0x15, 0x15, 0x11, 0x11}},
+    {'t', {0x08, 0x08, 0x1C, 0x08, 0x08, 0x09, 0x06}}, {'k', {0x10, 0x10, 0x12, 0x14, 0x18, 0x14, 0x12}},
+    {'n', {0x00, 0x00, 0x16, 0x19, 0x11, 0x11, 0x11}}, {'v', {0x00, 0x00, 0x11, 0x11, 0x11, 0x0A, 0x04}},
+};
+
+/* glyph rows of `ch`, or NULL: the NV12 text path skips unknown characters (:302) */
+const uint8_t* vto_glyph(char ch) {
+    for (size_t i = 0; i < sizeof(kFont) / sizeof(kFont[0]); ++i)
+        if (kFont[i].c == ch) return kFont[i].rows;
+    return NULL;
+}
+
+/* src/nv12_convert.rs:246-322 */
+void vto_draw_text_nv12(uint8_t* nv12, size_t width, size_t height, const char* text, size_t x,
+                        size_t y, size_t scale, uint8_t brightness) {
+    size_t cursor_x = x;
+    for (const char* p = text; *p; ++p) {
+        const uint8_t* glyph = vto_glyph(*p);
+        if (glyph)
+            for (size_t row = 0; row < 7; ++row)
+                for (size_t col = 0; col < 5; ++col)
+                    if ((glyph[row] >> (4 - col)) & 1)
+                        for (size_t dy = 0; dy < scale; ++dy)
+                            for (size_t dx = 0; dx < scale; ++dx) {
+                                size_t px = cursor_x + col * scale + dx, py = y + row * scale + dy;
+                                if (px < width && py < height) nv12[py * width + px] = brightness;
+                            }
+        cursor_x += 6 * scale;   /* advances for unknown characters too */
+    }
+}
+
+/* src/nv12_convert.rs:325-343 */
+void vto_draw_background_nv12(uint8_t* nv12, size_t width, size_t height, size_t x, size_t y,
+                              size_t w, size_t h, uint8_t darkness) {
+    uint16_t factor = (uint16_t)(255 - darkness);
+    for (size_t py = y; py < zmin(y + h, height); ++py)
+        for (size_t px = x; px < zmin(x + w, width); ++px) {
+            size_t idx = py * width + px;
+            nv12[idx] = (uint8_t)(((uint16_t)nv12[idx] * factor) / 255);
+        }
+}
+
+/* src/drawing.rs:5-23 */
+void vto_draw_cursor(uint8_t* data, size_t w, size_t h, int32_t x_, int32_t y_) {
+    int32_t xc = x_ < 0 ? 0 : (x_ > (int32_t)w - 1 ? (int32_t)w - 1 : x_);
+    int32_t yc = y_ < 0 ? 0 : (y_ > (int32_t)h - 1 ? (int32_t)h - 1 : y_);
+    size_t x = (size_t)xc, y = (size_t)yc;
+    for (size_t px = sat_sub(x, 25); px <= zmin(x + 25, w - 1); ++px)
+        if (!(px >= sat_sub(x, 5) && px <= x + 5)) data[y * w + px] = 255;
+    for (size_t py = sat_sub(y, 25); py <= zmin(y + 25, h - 1); ++py)
+        if (!(py >= sat_sub(y, 5) && py <= y + 5)) data[py * w + x] = 255;
+}
+
+/* src/drawing.rs:25-50 (the caller checks phase == SelectingArea) */
+void vto_draw_selection(uint8_t* data, size_t w, size_t h, int32_t start_x, int32_t start_y,
+                        int32_t cursor_x, int32_t cursor_y) {
+    int32_t mnx = start_x < cursor_x ? start_x : cursor_x, mny = start_y < cursor_y ? start_y : cursor_y;
+    int32_t mxx = start_x > cursor_x ? start_x : cursor_x, mxy = start_y > cursor_y ? start_y : cursor_y;
+    size_t x1 = (size_t)(mnx > 0 ? mnx : 0), y1 = (size_t)(mny > 0 ? mny : 0);
+    size_t x2 = zmin((size_t)(int64_t)mxx, w - 1), y2 = zmin((size_t)(int64_t)mxy, h - 1);
+    for (size_t x = x1; x <= x2; ++x)
+        if ((x / 6) % 2 == 0) { data[y1 * w + x] = 255; data[y2 * w + x] = 255; }
+    for (size_t y = y1; y <= y2; ++y)
+        if ((y / 6) % 2 == 0) { data[y * w + x1] = 255; data[y * w + x2] = 255; }
+}
