@@ -376,6 +376,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     }
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
+#ifdef VT_STAGGER
+    // experiment: offset the second block of each CU by about half a K-tile so that the two
+    // co-resident blocks alternate load and MFMA phases instead of running in lockstep
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(VT_STAGGER);
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WVN, wc = wave % WVN, l31 = lane & 31, half = lane >> 5;
 
