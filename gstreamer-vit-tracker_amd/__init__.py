@@ -83,7 +83,8 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device",
+    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_attention_bench", "vt_op_layernorm",
@@ -153,6 +154,8 @@ def lib():
     L.vt_overlay_nv12_device.argtypes = [c_int, c_void_p, c_int, c_int, c_int, POINTER(CDrawCmd), c_int,
                                          c_void_p]
     L.vt_overlay_nv12.argtypes = [c_int, u8p, c_int, c_int, POINTER(CDrawCmd), c_int]
+    L.vt_overlay_rgb8_device.argtypes = L.vt_overlay_nv12_device.argtypes
+    L.vt_overlay_rgb8.argtypes = L.vt_overlay_nv12.argtypes
     u16p, fp = POINTER(c_uint16), POINTER(c_float)
     L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int]
     L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
@@ -462,6 +465,15 @@ def overlay_nv12(nv12: np.ndarray, width: int, height: int, cmds, device: int = 
     arr = (CDrawCmd * len(cmds))(*cmds)
     _check(lib().vt_overlay_nv12(device, _u8(buf), width, height, arr, len(cmds)))
     return buf
+
+
+def overlay_rgb8(rgb: np.ndarray, cmds, device: int = 0) -> np.ndarray:
+    """apply draw commands to an (H,W,3) RGB8 host image (returns a copy)"""
+    img = np.ascontiguousarray(rgb, np.uint8).copy()
+    h, w, _ = img.shape
+    arr = (CDrawCmd * len(cmds))(*cmds)
+    _check(lib().vt_overlay_rgb8(device, _u8(img), w, h, arr, len(cmds)))
+    return img
 
 
 # ---- operator-level entry points (numerics tests) -------------------------------------------

@@ -132,3 +132,88 @@ hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, co
     hipLaunchKernelGGL(overlay_kernel, grid, dim3(256), 0, st, yplane, width, height, stride, d_cmds, n);
     return hipGetLastError();
 }
+
+// ---- packed RGB8 surface (src/drawing_rgb.rs:4-129) -----------------------------------------------------
+// Same scheme; every write goes through set_pixel_rgb_color's bounds test, so coverage is the plain
+// geometric shape clipped to the frame. value = 0xRRGGBB (text: r = g = b = value & 255).
+__device__ __forceinline__ bool covers_rgb(const vt_draw_cmd& c, int px, int py, int W, int H) {
+    switch (c.type) {
+        case VT_DRAW_BACKGROUND: {  // :30-53 (fill with 30)
+            const u64 xs = (u64)(c.x > 0 ? c.x : 0), xe = umin(as_usize(c.x + c.w), (u64)W);
+            const u64 ys = (u64)(c.y > 0 ? c.y : 0), ye = umin(as_usize(c.y + c.h), (u64)H);
+            return xe >= xs && (u64)px >= xs && (u64)px < xe && (u64)py >= ys && (u64)py < ye;
+        }
+        case VT_DRAW_TEXT: {        // :86-104
+            const int sc = c.p;
+            if (sc <= 0) return false;
+            const long long dx = (long long)px - c.x, dy = (long long)py - c.y;
+            if (dx < 0 || dy < 0) return false;
+            const long long row = dy / sc, ci = dx / (6LL * sc), col = (dx % (6LL * sc)) / sc;
+            if (row >= 7 || col >= 5 || ci >= (long long)sizeof(c.text)) return false;
+            for (long long k = 0; k <= ci; ++k)
+                if (c.text[k] == 0) return false;
+            return glyph_bit(c.text[ci], (int)row, (int)col);
+        }
+        case VT_DRAW_RECT: {        // :55-66
+            const long long rx = (long long)px - c.x, ry = (long long)py - c.y, th = c.p;
+            const bool in_w = rx >= 0 && rx < c.w, in_h = ry >= 0 && ry < c.h;
+            // rows y+t and y+rh-1-t for i in 0..rw; columns x+t and x+rw-1-t for i in 0..rh
+            if (in_w && ((ry >= 0 && ry < th) || (c.h - 1 - ry >= 0 && c.h - 1 - ry < th))) return true;
+            if (in_h && ((rx >= 0 && rx < th) || (c.w - 1 - rx >= 0 && c.w - 1 - rx < th))) return true;
+            return false;
+        }
+        case VT_DRAW_CROSSHAIR: {   // :68-73
+            const long long dx = (long long)px - c.x, dy = (long long)py - c.y;
+            return (dy == 0 && dx >= -(long long)c.p && dx <= c.p) || (dx == 0 && dy >= -(long long)c.p && dy <= c.p);
+        }
+        case VT_DRAW_CURSOR: {      // :75-84, arms 5..=25
+            const long long dx = (long long)px - c.x, dy = (long long)py - c.y;
+            const long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+            return (dy == 0 && ax >= 5 && ax <= 25) || (dx == 0 && ay >= 5 && ay <= 25);
+        }
+        case VT_DRAW_SELECTION: {   // :106-129: start = (x, y), cursor = (w, h)
+            int x1 = c.x < c.w ? c.x : c.w, y1 = c.y < c.h ? c.y : c.h;
+            int x2 = c.x > c.w ? c.x : c.w, y2 = c.y > c.h ? c.y : c.h;
+            x1 = x1 > 0 ? x1 : 0; y1 = y1 > 0 ? y1 : 0;
+            x2 = x2 < W - 1 ? x2 : W - 1; y2 = y2 < H - 1 ? y2 : H - 1;
+            if ((py == y1 || py == y2) && px >= x1 && px <= x2 && (px / 6) % 2 == 0) return true;
+            if ((px == x1 || px == x2) && py >= y1 && py <= y2 && (py / 6) % 2 == 0) return true;
+            return false;
+        }
+        default: return false;
+    }
+}
+
+__global__ __launch_bounds__(256) void overlay_rgb_kernel(uint8_t* __restrict__ rgb, int width, int height,
+                                                          int stride, const vt_draw_cmd* __restrict__ cmds,
+                                                          int n) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= width || py >= height) return;
+    int r = 0, g = 0, b = 0;
+    bool hit = false;
+    for (int i = 0; i < n; ++i) {
+        const vt_draw_cmd& c = cmds[i];
+        if (!covers_rgb(c, px, py, width, height)) continue;
+        hit = true;
+        switch (c.type) {
+            case VT_DRAW_BACKGROUND: r = g = b = 30; break;
+            case VT_DRAW_TEXT: r = g = b = c.value & 255; break;
+            case VT_DRAW_CURSOR: r = 0; g = 255; b = 0; break;
+            case VT_DRAW_SELECTION: r = 255; g = 255; b = 0; break;
+            default: r = (c.value >> 16) & 255; g = (c.value >> 8) & 255; b = c.value & 255; break;
+        }
+    }
+    if (hit) {
+        uint8_t* p = rgb + (size_t)py * stride + (size_t)px * 3;
+        p[0] = (uint8_t)r; p[1] = (uint8_t)g; p[2] = (uint8_t)b;
+    }
+}
+
+hipError_t launch_overlay_rgb(uint8_t* rgb, int width, int height, int stride, const vt_draw_cmd* d_cmds, int n,
+                              hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    dim3 grid((width + 63) / 64, (height + 3) / 4);
+    hipLaunchKernelGGL(overlay_rgb_kernel, grid, dim3(256), 0, st, rgb, width, height, stride, d_cmds, n);
+    return hipGetLastError();
+}

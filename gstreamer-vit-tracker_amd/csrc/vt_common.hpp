@@ -95,6 +95,9 @@ hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C
 hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, const vt_draw_cmd* d_cmds,
                           int n, hipStream_t st);
 
+hipError_t launch_overlay_rgb(uint8_t* rgb, int width, int height, int stride, const vt_draw_cmd* d_cmds,
+                              int n, hipStream_t st);
+
 struct DecodeArgs {
     const bf16_t* t3;       // [B*ns][C]
     const float* w4;        // [8][C]

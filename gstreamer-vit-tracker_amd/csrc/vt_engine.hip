@@ -1057,9 +1057,9 @@ struct DevBuf {
 
 // ---- overlays ---------------------------------------------------------------------------------------------
 
-int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int stride, const vt_draw_cmd* cmds,
-                           int n, void* hip_stream) {
-    if (!d_y || width <= 0 || height <= 0 || stride < width || n < 0 || (n > 0 && !cmds))
+static int overlay_device(int device_id, void* d_surf, int width, int height, int stride, int min_stride,
+                          const vt_draw_cmd* cmds, int n, void* hip_stream, bool rgb) {
+    if (!d_surf || width <= 0 || height <= 0 || stride < min_stride || n < 0 || (n > 0 && !cmds))
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (n == 0) return VT_OK;
     if (n > 256) return set_err(VT_ERR_INVALID_ARG, "at most 256 draw commands per call");
@@ -1068,26 +1068,43 @@ int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int 
     hipStream_t st = (hipStream_t)hip_stream;
     vt_draw_cmd* d_cmds = nullptr;
     HIPCHK(hipMallocAsync((void**)&d_cmds, sizeof(vt_draw_cmd) * n, st));
+    // pageable source: hipMemcpyAsync has consumed `cmds` when it returns
     hipError_t e = hipMemcpyAsync(d_cmds, cmds, sizeof(vt_draw_cmd) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = launch_overlay((uint8_t*)d_y, width, height, stride, d_cmds, n, st);
+    if (e == hipSuccess)
+        e = rgb ? launch_overlay_rgb((uint8_t*)d_surf, width, height, stride, d_cmds, n, st)
+                : launch_overlay((uint8_t*)d_surf, width, height, stride, d_cmds, n, st);
     (void)hipFreeAsync(d_cmds, st);
     if (e != hipSuccess) return set_err(VT_ERR_HIP, "overlay: %s", hipGetErrorString(e));
-    // pageable source: hipMemcpyAsync has consumed `cmds` when it returns
     return VT_OK;
 }
 
-int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds, int n) {
-    if (!nv12 || width <= 0 || height <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+static int overlay_host(int device_id, uint8_t* surf, size_t bytes, int width, int height, int stride,
+                        const vt_draw_cmd* cmds, int n, bool rgb) {
+    if (!surf || width <= 0 || height <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    DevBuf dy;
-    const size_t bytes = (size_t)width * height;
-    HIPCHK(dy.alloc(bytes));
-    HIPCHK(hipMemcpy(dy.p, nv12, bytes, hipMemcpyHostToDevice));
-    if (int rc = vt_overlay_nv12_device(device_id, dy.p, width, height, width, cmds, n, nullptr)) return rc;
+    DevBuf d;
+    HIPCHK(d.alloc(bytes));
+    HIPCHK(hipMemcpy(d.p, surf, bytes, hipMemcpyHostToDevice));
+    if (int rc = overlay_device(device_id, d.p, width, height, stride, stride, cmds, n, nullptr, rgb)) return rc;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(nv12, dy.p, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(surf, d.p, bytes, hipMemcpyDeviceToHost));
     return VT_OK;
+}
+
+int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int stride, const vt_draw_cmd* cmds,
+                           int n, void* hip_stream) {
+    return overlay_device(device_id, d_y, width, height, stride, width, cmds, n, hip_stream, false);
+}
+int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds, int n) {
+    return overlay_host(device_id, nv12, (size_t)width * height, width, height, width, cmds, n, false);
+}
+int vt_overlay_rgb8_device(int device_id, void* d_rgb, int width, int height, int stride, const vt_draw_cmd* cmds,
+                           int n, void* hip_stream) {
+    return overlay_device(device_id, d_rgb, width, height, stride, width * 3, cmds, n, hip_stream, true);
+}
+int vt_overlay_rgb8(int device_id, uint8_t* rgb, int width, int height, const vt_draw_cmd* cmds, int n) {
+    return overlay_host(device_id, rgb, (size_t)width * height * 3, width, height, width * 3, cmds, n, true);
 }
 
 // ---- operator-level entry points ---------------------------------------------------------------------------

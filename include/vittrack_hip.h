@@ -216,6 +216,13 @@ int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int 
 /* Host-pointer form: draws into the packed NV12 buffer (stride == width) in place. */
 int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds,
                     int n);
+/* The packed-RGB8 variants the reference's live pipeline uses (src/drawing_rgb.rs:30-129,
+ * src/pipeline_ir.rs:168-202): same command list; value = 0xRRGGBB for rect / crosshair, luma for
+ * text; background fills with 30, cursor is (0,255,0), selection (255,255,0) as in the reference. */
+int vt_overlay_rgb8_device(int device_id, void* d_rgb, int width, int height, int stride,
+                           const vt_draw_cmd* cmds, int n, void* hip_stream);
+int vt_overlay_rgb8(int device_id, uint8_t* rgb, int width, int height, const vt_draw_cmd* cmds,
+                    int n);
 
 /* ---- per-kernel timing and stage taps (parity tests, bench roofline) -------------------- */
 

@@ -52,6 +52,12 @@ def lib():
         _lib.vto_draw_background_nv12.argtypes = [c_u8p, sz, sz, sz, sz, sz, sz, u8]
         _lib.vto_draw_cursor.argtypes = [c_u8p, sz, sz, i32, i32]
         _lib.vto_draw_selection.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32]
+        _lib.vto_draw_background_rgb.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32]
+        _lib.vto_draw_rect_rgb.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32, i32, u8, u8, u8]
+        _lib.vto_draw_crosshair_rgb.argtypes = [c_u8p, sz, sz, i32, i32, i32, u8, u8, u8]
+        _lib.vto_draw_cursor_rgb.argtypes = [c_u8p, sz, sz, i32, i32]
+        _lib.vto_draw_text_rgb.argtypes = [c_u8p, sz, sz, ctypes.c_char_p, i32, i32, i32, u8]
+        _lib.vto_draw_selection_rgb.argtypes = [c_u8p, sz, sz, i32, i32, i32, i32]
         _lib.vto_decode.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
                                     c_fp, ctypes.POINTER(ctypes.c_int32)]
     return _lib
@@ -120,6 +126,28 @@ def draw(nv12: np.ndarray, w: int, h: int, cmds) -> np.ndarray:
         elif kind == 5:
             L.vto_draw_selection(p, w, h, x, y, cw, ch)
     return buf
+
+
+def draw_rgb(img: np.ndarray, cmds) -> np.ndarray:
+    """the packed-RGB variants (src/drawing_rgb.rs); value = 0xRRGGBB for rect / crosshair"""
+    out = np.ascontiguousarray(img, np.uint8).copy()
+    h, w, _ = out.shape
+    L, p = lib(), _u8p(out)
+    for (kind, x, y, cw, ch, pp, value, text) in cmds:
+        r, g, b = (value >> 16) & 255, (value >> 8) & 255, value & 255
+        if kind == 0:
+            L.vto_draw_background_rgb(p, w, h, x, y, cw, ch)
+        elif kind == 1:
+            L.vto_draw_text_rgb(p, w, h, text.encode(), x, y, pp, value & 255)
+        elif kind == 2:
+            L.vto_draw_rect_rgb(p, w, h, x, y, cw, ch, pp, r, g, b)
+        elif kind == 3:
+            L.vto_draw_crosshair_rgb(p, w, h, x, y, pp, r, g, b)
+        elif kind == 4:
+            L.vto_draw_cursor_rgb(p, w, h, x, y)
+        elif kind == 5:
+            L.vto_draw_selection_rgb(p, w, h, x, y, cw, ch)
+    return out
 
 
 # ---- frames ---------------------------------------------------------------------------------
@@ -315,7 +343,8 @@ class VitTrackRef:
         score = float(dec[0])
         success = bool(score >= self.thr)
         if success:
-            self.box = dec[1:5].astype(np.float32).copy()
+            # next crop is cut around the INTEGER box the caller sees
+            self.box = ib.astype(np.float32).copy()
         if taps:
             out["patches"] = patches
             out["geo"] = geo

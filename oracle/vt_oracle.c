@@ -441,3 +441,94 @@ void vto_draw_selection(uint8_t* data, size_t w, size_t h, int32_t start_x, int3
     for (size_t y = y1; y <= y2; ++y)
         if ((y / 6) % 2 == 0) { data[y * w + x1] = 255; data[y * w + x2] = 255; }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Overlay drawing on packed RGB8   (reference: src/drawing_rgb.rs:4-129; the variant `main` runs)
+ * ------------------------------------------------------------------------------------------- */
+
+/* src/drawing_rgb.rs:17-28 (set_pixel_rgb :4-15 is the r = g = b case) */
+static inline void set_px(uint8_t* d, size_t len, size_t w, int32_t x, int32_t y, size_t h, uint8_t r,
+                          uint8_t g, uint8_t b) {
+    if (x < 0 || y < 0 || x >= (int32_t)w || y >= (int32_t)h) return;
+    size_t off = ((size_t)y * w + (size_t)x) * 3;
+    if (off + 2 < len) { d[off] = r; d[off + 1] = g; d[off + 2] = b; }
+}
+
+/* src/drawing_rgb.rs:30-53: fills with 30, no read (an inverted range panics in the reference) */
+void vto_draw_background_rgb(uint8_t* d, size_t w, size_t h, int32_t x, int32_t y, int32_t bw, int32_t bh) {
+    size_t xs = (size_t)(x > 0 ? x : 0), xe = zmin((size_t)(int64_t)(x + bw), w);
+    size_t ys = (size_t)(y > 0 ? y : 0), ye = zmin((size_t)(int64_t)(y + bh), h);
+    if (xe < xs) return;
+    for (size_t row = ys; row < ye; ++row) memset(d + (row * w + xs) * 3, 30, (xe - xs) * 3);
+}
+
+/* src/drawing_rgb.rs:55-66 */
+void vto_draw_rect_rgb(uint8_t* d, size_t w, size_t h, int32_t x, int32_t y, int32_t rw, int32_t rh,
+                       int32_t thickness, uint8_t r, uint8_t g, uint8_t b) {
+    size_t len = w * h * 3;
+    for (int32_t t = 0; t < thickness; ++t) {
+        for (int32_t i = 0; i < rw; ++i) {
+            set_px(d, len, w, x + i, y + t, h, r, g, b);
+            set_px(d, len, w, x + i, y + rh - 1 - t, h, r, g, b);
+        }
+        for (int32_t i = 0; i < rh; ++i) {
+            set_px(d, len, w, x + t, y + i, h, r, g, b);
+            set_px(d, len, w, x + rw - 1 - t, y + i, h, r, g, b);
+        }
+    }
+}
+
+/* src/drawing_rgb.rs:68-73 */
+void vto_draw_crosshair_rgb(uint8_t* d, size_t w, size_t h, int32_t cx, int32_t cy, int32_t size,
+                            uint8_t r, uint8_t g, uint8_t b) {
+    size_t len = w * h * 3;
+    for (int32_t i = -size; i <= size; ++i) {
+        set_px(d, len, w, cx + i, cy, h, r, g, b);
+        set_px(d, len, w, cx, cy + i, h, r, g, b);
+    }
+}
+
+/* src/drawing_rgb.rs:75-84 */
+void vto_draw_cursor_rgb(uint8_t* d, size_t w, size_t h, int32_t cx, int32_t cy) {
+    size_t len = w * h * 3;
+    for (int32_t i = 5; i <= 25; ++i) {
+        set_px(d, len, w, cx + i, cy, h, 0, 255, 0);
+        set_px(d, len, w, cx - i, cy, h, 0, 255, 0);
+        set_px(d, len, w, cx, cy + i, h, 0, 255, 0);
+        set_px(d, len, w, cx, cy - i, h, 0, 255, 0);
+    }
+}
+
+/* src/drawing_rgb.rs:86-104; unknown characters: get_glyph returns Err (src/drawing.rs:99) -> skipped */
+void vto_draw_text_rgb(uint8_t* d, size_t w, size_t h, const char* text, int32_t x, int32_t y,
+                       int32_t scale, uint8_t luma) {
+    size_t len = w * h * 3;
+    int32_t cx = x;
+    for (const char* p = text; *p; ++p) {
+        const uint8_t* glyph = vto_glyph(*p);
+        if (glyph)
+            for (int32_t gy = 0; gy < 7; ++gy)
+                for (int32_t gx = 0; gx < 5; ++gx)
+                    if ((glyph[gy] >> (4 - gx)) & 1)
+                        for (int32_t sy = 0; sy < scale; ++sy)
+                            for (int32_t sx = 0; sx < scale; ++sx)
+                                set_px(d, len, w, cx + gx * scale + sx, y + gy * scale + sy, h, luma, luma, luma);
+        cx += 6 * scale;
+    }
+}
+
+/* src/drawing_rgb.rs:106-129 (the caller checks the phase) */
+void vto_draw_selection_rgb(uint8_t* d, size_t w, size_t h, int32_t start_x, int32_t start_y,
+                            int32_t cursor_x, int32_t cursor_y) {
+    size_t len = w * h * 3;
+    int32_t x1 = start_x < cursor_x ? start_x : cursor_x, y1 = start_y < cursor_y ? start_y : cursor_y;
+    int32_t x2 = start_x > cursor_x ? start_x : cursor_x, y2 = start_y > cursor_y ? start_y : cursor_y;
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    if (x2 > (int32_t)w - 1) x2 = (int32_t)w - 1;
+    if (y2 > (int32_t)h - 1) y2 = (int32_t)h - 1;
+    for (int32_t x = x1; x <= x2; ++x)
+        if ((x / 6) % 2 == 0) { set_px(d, len, w, x, y1, h, 255, 255, 0); set_px(d, len, w, x, y2, h, 255, 255, 0); }
+    for (int32_t y = y1; y <= y2; ++y)
+        if ((y / 6) % 2 == 0) { set_px(d, len, w, x1, y, h, 255, 255, 0); set_px(d, len, w, x2, y, h, 255, 255, 0); }
+}

@@ -98,3 +98,36 @@ def test_gpu_overlay_probe_frame_1080p(gpu, oracle):
     got = gpu.overlay_nv12(base, w, h, [gpu.draw_cmd(*c) for c in cmds])
     assert np.array_equal(got, want)
     assert not np.array_equal(got, base)
+
+
+def test_oracle_rgb_variants(oracle):
+    img = np.full((H, W, 3), 100, np.uint8)
+    out = oracle.draw_rgb(img, [(2, 10, 8, 20, 12, 2, 0xFF8000, "")])
+    assert (out[8:10, 10:30] == (255, 128, 0)).all() and (out[18:20, 10:30] == (255, 128, 0)).all()
+    assert (out[8:20, 10:12] == (255, 128, 0)).all() and (out[8:20, 28:30] == (255, 128, 0)).all()
+    assert (out[12, 15] == 100).all() and (out[8, 30] == 100).all()       # x + rw is exclusive here
+    out = oracle.draw_rgb(img, [(0, -5, -5, 20, 10, 0, 0, "")])
+    assert (out[0:5, 0:15] == 30).all() and (out[5, 0] == 100).all() and (out[0, 15] == 100).all()
+    out = oracle.draw_rgb(img, [(4, 48, 32, 0, 0, 0, 0, "")])
+    assert (out[32, 53:74] == (0, 255, 0)).all() and (out[32, 49:53] == 100).all() and (out[7:28, 48] == (0, 255, 0)).all()
+    out = oracle.draw_rgb(img, [(5, 12, 6, 40, 30, 0, 0, "")])
+    assert (out[6, 12] == (255, 255, 0)).all() and (out[6, 18] == 100).all()
+    # clipped by set_pixel's bounds test, no wrap quirks in this variant
+    out = oracle.draw_rgb(img, [(3, -3, 2, 0, 0, 6, 0x0000FF, "")])
+    assert (out[2, 0:4] == (0, 0, 255)).all() and (out[2, 4] == 100).all()
+
+
+@pytest.mark.gpu
+def test_gpu_overlay_rgb_bit_exact_random_command_lists(gpu, oracle):
+    rng = np.random.default_rng(7)
+    for trial in range(30):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        cmds = []
+        for c in _random_cmds(rng, int(rng.integers(1, 12))):
+            k, x, y, w, h, p, v, text = c
+            if k == 0 and (w < 0 or h < 0):
+                w, h = abs(w), abs(h)            # an inverted background range panics in the reference
+            cmds.append((k, x, y, w, h, p, int(rng.integers(0, 1 << 24)), text))
+        want = oracle.draw_rgb(img, cmds)
+        got = gpu.overlay_rgb8(img, [gpu.draw_cmd(*c) for c in cmds])
+        assert np.array_equal(got, want), (trial, cmds)
