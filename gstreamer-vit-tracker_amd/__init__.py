@@ -85,7 +85,7 @@ EXPORTS = [
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
     "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
-    "vt_group_profile_device", "vt_group_enable_taps", "vt_tracker_as_group",
+    "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_attention_bench", "vt_op_layernorm",
 ]
@@ -144,6 +144,7 @@ def lib():
     L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
                                           POINTER(CKernelTime), c_int]
     L.vt_group_enable_taps.argtypes = [c_void_p, c_int]
+    L.vt_group_set_state_box.argtypes = [c_void_p, c_int, POINTER(c_float)]
     L.vt_tracker_as_group.argtypes = [c_void_p]
     L.vt_tracker_as_group.restype = c_void_p
     L.vt_group_read_tensor.argtypes = [c_void_p, c_int, c_char_p, POINTER(c_float), c_int64]
@@ -424,6 +425,10 @@ class Group:
         return [dict(name=out[i].name.decode(), launches=out[i].launches,
                      ms=float(out[i].ms_total), flops=out[i].flops, bytes=out[i].bytes)
                 for i in range(n)]
+
+    def set_state_box(self, stream: int, box):
+        b = (c_float * 4)(*[float(v) for v in box])
+        _check(lib().vt_group_set_state_box(self._h, stream, b))
 
     def enable_taps(self, on=True):
         _check(lib().vt_group_enable_taps(self._h, 1 if on else 0))

@@ -724,6 +724,19 @@ int vt_group_enable_taps(vt_group* g, int enable) {
     return VT_OK;
 }
 
+int vt_group_set_state_box(vt_group* g, int stream, const float* box4) {
+    if (!g || !box4) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
+    if (!e->h_initialized[stream]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", stream);
+    if (!(box4[2] >= 1.0f) || !(box4[3] >= 1.0f)) return set_err(VT_ERR_INVALID_ARG, "box size < 1");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_states[stream].box, box4, 4 * sizeof(float), hipMemcpyHostToDevice));
+    memcpy(e->h_states_all[stream].box, box4, 4 * sizeof(float));
+    return VT_OK;
+}
+
 int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iters,
                             vt_kernel_time* out, int max_out) {
     if (!g || !frames || !out || iters < 1) return set_err(VT_ERR_INVALID_ARG, "bad argument");

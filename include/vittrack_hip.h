@@ -247,6 +247,11 @@ int vt_group_enable_taps(vt_group* g, int enable);
  * thread-local and valid until the next call of this function on the same thread. */
 vt_group* vt_tracker_as_group(vt_tracker* t);
 
+/* Overwrite the box the next update of `stream` crops its search window around (x, y, w, h in frame
+ * pixels). Tooling hook: lets a caller evaluate the network on a window of its choosing (head
+ * training data, stage tests) while keeping the template set by vt_group_init_device. */
+int vt_group_set_state_box(vt_group* g, int stream, const float* box4);
+
 /* Copy an intermediate tensor of the last pass to the host as float32.
  * names: "patches" [N,Kpad], "tokens0" [N,D], "layer<i>" [N,D] (residual stream after block i;
  * both need taps), "x" [N,D] (final residual stream), "attn" [N,D] (last block's attention output),
