@@ -23,14 +23,14 @@ LIB_HIP = os.path.join(PKG, "libvittrack_hip.so")
 LIB_HOST = os.path.join(PKG, "libvittrack_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "k_overlay.hip",
+HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_gemm256.hip", "k_attn.hip", "k_misc.hip", "k_overlay.hip",
                "vt_engine.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",
              "-Wno-unused-function"]
 # fused multiply-add allowed where no bit-exact float spec applies (MFMA kernels' epilogues and
 # softmax); the pixel stage and the box decode keep one IEEE operation per source operation
-FAST_CONTRACT = {"k_gemm.hip", "k_attn.hip"}
+FAST_CONTRACT = {"k_gemm.hip", "k_gemm256.hip", "k_attn.hip"}
 HOST_SOURCES = ["host_capi.cpp"]
 
 
@@ -52,7 +52,7 @@ def _run(cmd: list[str]) -> None:
 
 def build_hip(force: bool = False, save_temps: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "vt_common.hpp"),
+    headers = [os.path.join(CSRC, "vt_common.hpp"), os.path.join(CSRC, "k_gemm_util.hpp"),
                os.path.join(PKG, "..", "include", "vittrack_hip.h")]
     objs, jobs = [], []
     for s in HIP_SOURCES:

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "vt_common.hpp"
+#include "k_gemm_util.hpp"
 
 #define GEMM_BK 64
 #define ROW_BYTES 128
@@ -39,39 +40,9 @@ __host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn) {
     return ring_depth(ns) * (bm + bn) * tile_bk(ns) * 2;
 }
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)gsrc,
-        (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
-// far below the bf16 rounding of the result): one v_rcp, one v_exp and a degree-5 polynomial
-// instead of libm's erff (~3x the instructions), which made the fc1 epilogue a visible share of
-// the kernel at large tiles.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    // erf(|x|/sqrt2) = 1 - poly*t*exp(-z^2); exp(-z^2) = 2^(-z^2 log2 e)
-    const float g = poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float erfv = __builtin_copysignf(1.0f - g, x);
-    const float hx = 0.5f * x;
-    return __builtin_fmaf(hx, erfv, hx);
-}
-
 // accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile
 __device__ __forceinline__ int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int WVM, int WVN, int NSX, bool ROW_ON_LANE>
@@ -564,7 +535,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(14, 128, 128, 2, 2, 36, EPI) \
     X(15, 256, 256, 2, 4, 36, EPI) \
     X(16, 128, 256, 2, 4, 35, EPI)
-#define GEMM_NUM_CFG 17
+#define GEMM_NUM_CFG 18   // 0..16: this file's template; 17: k_gemm256.hip
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
@@ -592,7 +563,8 @@ hipError_t gemm_prepare() {
     if ((e = prepare_epi<EPI_GELU_BF16>()) != hipSuccess) return e;
     if ((e = prepare_epi<EPI_RELU_BF16>()) != hipSuccess) return e;
     if ((e = prepare_epi<EPI_QKV>()) != hipSuccess) return e;
-    return prepare_epi<EPI_F32>();
+    if ((e = prepare_epi<EPI_F32>()) != hipSuccess) return e;
+    return gemm256_prepare();
 }
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
@@ -614,6 +586,13 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
     if (forced >= 0 && forced < GEMM_NUM_CFG) return forced;
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
+    // 256x256 8-wave kernel (k_gemm256.hip): one workgroup per CU, so it wants the grid to fill
+    // the 256 CUs in whole rounds; measured against 128x128 on the tracker's shapes it wins from
+    // about half a round upwards unless the last round is nearly empty (profiles/gemm_sweep_r01.txt)
+    if ((N % 256) == 0 && K >= 128 && epilogue != EPI_F32_POS) {
+        const long t = (long)((M + 255) / 256) * (N / 256), rounds = (t + 255) / 256;
+        if (t >= 128 && (rounds == 1 || t * 10 >= rounds * 256 * 6)) return GEMM_CFG_256P8;
+    }
     switch (epilogue) {
         case EPI_QKV:
         case EPI_GELU_BF16: return (n128 && tiles128 >= 400) ? 3 : 2;
@@ -629,7 +608,7 @@ const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "256x256x2",
                               "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3", "128x128rs",
                               "64x64rs", "256x256rs", "256x128rs", "256x128k32x3", "128x128k32x4",
-                              "256x256k32x4", "128x256k32x3"};
+                              "256x256k32x4", "128x256k32x3", "256x256p8"};
     return (cfg >= 0 && cfg < GEMM_NUM_CFG) ? n[cfg] : "?";
 }
 
@@ -648,6 +627,7 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
         return hipErrorInvalidValue;
+    if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, st);
     switch (epilogue) {
         case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
         case EPI_RESID: return launch_epi<EPI_RESID>(a, cfg, st);

@@ -1,0 +1,443 @@
+// k_gemm256.hip — 256x256-tile, 8-wave, phase-interleaved bf16 MFMA GEMM for gfx950 (config 17).
+//
+//   C[M,N] = A[M,K] · W[N,K]^T (+ the fused epilogues of k_gemm.hip), one 256x256 output tile per
+//   workgroup, one workgroup per CU (128 KiB of LDS, 512 threads).
+//
+// Why a second kernel: the 128x128 / 4-wave kernel of k_gemm.hip is bounded by the rate at which a
+// CU gets operand tiles from L2 (profiles/README.md: the block parks on s_waitcnt vmcnt for 43 %
+// of its cycles). A 256x256 tile moves half the bytes per FLOP, and the schedule below keeps four
+// half-tiles (64 KiB) per CU in flight at all times, issued 5-6 phases before they are needed.
+//
+// Geometry
+//   * 8 waves as 2 (M) x 4 (N); a wave owns a 128 x 64 piece of C = 8 x 4 v_mfma_f32_16x16x32_bf16
+//     accumulators (128 VGPRs). It is computed as four 64 x 32 quadrants (i, j), one per PHASE,
+//     16 MFMAs each, in the order (0,0) (0,1) (1,1) (1,0).
+//   * K-tile depth 64. One K-tile in LDS = four HALF-tiles of 16 KiB, each 128 rows x 128 B:
+//       A_i = the rows every wave uses for quadrant row i  (rows wr*128 + i*64 + 0..63, wr = 0,1)
+//       B_j = the W rows every wave uses for quadrant column j (wc*64 + j*32 + 0..31, wc = 0..3)
+//     so that a half-tile is dead as soon as its phase has read it: A0 and B0 after phase 1 (B0
+//     and B1 stay in registers), B1 after phase 2, A1 after phase 3. Two K-tile buffers (128 KiB).
+//   * LDS image as in k_gemm.hip: 128-B rows, 16-B chunk c of row r stored at c ^ ((r >> 1) & 7);
+//     LDS-DMA (global_load_lds_dwordx4) writes lane-linear, so the XOR sits on the per-lane SOURCE
+//     address and again on the ds_read_b128 (conflict-free for 16-row fragments too: the 16 lanes
+//     of each read group land on 16 distinct 16-B slots of the 256-B bank row).
+//
+// Schedule (per K-tile t, buffer t & 1; one half-tile = 2 LDS-DMA instructions per thread)
+//     phase 1: read B0, A0(t)   stage B1(t+1)   wait vmcnt(8)  | barrier | MFMA (0,0) | barrier
+//     phase 2: read B1(t)       stage A1(t+1)   wait vmcnt(8)  | barrier | MFMA (0,1) | barrier
+//     phase 3: read A1(t)       stage A0(t+2)                  | barrier | MFMA (1,1) | barrier
+//     phase 4: —                stage B0(t+2)   wait vmcnt(8)  | barrier | MFMA (1,0) | barrier
+//   The two wave rows run one barrier apart (wr = 1 executes one extra s_barrier before the loop,
+//   wr = 0 one after it), so on every SIMD one wave is in its MFMA section while the other reads
+//   LDS and issues loads.
+//   Ordering rules this relies on (MI355X guide, "Read a staged buffer one phase AFTER the wait
+//   that retires it"):
+//     RAW  a half-tile is read in phase p only if every wave executed the counted vmcnt that
+//          retires it before the first barrier of a phase <= p-1: A0/B0(t+1) are retired in phase
+//          4 of tile t and read in phase 1 of t+1; B1(t+1) in phase 1 / read in 2; A1(t+1) in
+//          phase 2 / read in 3. vmcnt retires in issue order, and at each wait exactly four
+//          younger half-tiles (8 instructions) may stay in flight.
+//     WAR  a half-tile is overwritten no earlier than two phases after its last read (A0(t+2) in
+//          phase 3 is the tightest: A0(t) was last read in phase 1); every reader has waited
+//          lgkmcnt(0) for those reads before the MFMAs of the reading phase, i.e. before the
+//          second barrier of that phase, and the other wave row is at most one barrier behind.
+//   The last two K-tiles stage less and use the correspondingly smaller counts (TAIL 1, 2).
+//
+// Epilogues go through LDS (dead after the loop) so that global stores are whole rows:
+// f32 outputs in two passes of 128 rows x 1 KiB, bf16 outputs in one pass of 256 rows x 512 B.
+#include "vt_common.hpp"
+#include "k_gemm_util.hpp"
+
+#define G256_BUF 65536
+#define G256_HALF 16384
+#define G256_LDS (2 * G256_BUF)
+
+namespace {
+
+typedef f32x4_t acc256_t[2][4][2][2];   // [i][mf][j][nf]
+
+template <bool SWAP>
+__device__ __forceinline__ f32x4_t mma16(const bf16x8_t& xa, const bf16x8_t& wb, const f32x4_t& c) {
+    // SWAP: D = W-frag · X-frag^T, lane = row of C (l & 15), registers = 4 consecutive columns
+    // else: D = X-frag · W-frag^T, lane = column of C,       registers = 4 consecutive rows
+    if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, c, 0, 0, 0);
+}
+
+#define G256_RD(ptr, off) (*reinterpret_cast<const bf16x8_t*>((ptr) + (off)))
+
+#define G256_READ_A(I)                                                        \
+    _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                        \
+        Af[mf][0] = G256_RD(pa0, (I) * G256_HALF + mf * 2048);                \
+        Af[mf][1] = G256_RD(pa1, (I) * G256_HALF + mf * 2048);                \
+    }
+#define G256_READ_B(J)                                                        \
+    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                        \
+        Bf[J][nf][0] = G256_RD(pb0, (J) * G256_HALF + nf * 2048);             \
+        Bf[J][nf][1] = G256_RD(pb1, (J) * G256_HALF + nf * 2048);             \
+    }
+// half-tile h of K-tile KT into the buffer at byte offset BO: 2 LDS-DMA instructions per thread
+#define G256_STAGE_A(I, KT, BO)                                                                  \
+    {                                                                                            \
+        const char* s_ = reinterpret_cast<const char*>(p.A) + (size_t)(KT) * 128;                \
+        char* d_ = smem + (BO) + (I) * G256_HALF + wave * 1024;                                  \
+        glds16(s_ + ((I) ? aoff10 : aoff00), d_);                                                \
+        glds16(s_ + ((I) ? aoff11 : aoff01), d_ + 8192);                                         \
+    }
+#define G256_STAGE_B(J, KT, BO)                                                                  \
+    {                                                                                            \
+        const char* s_ = reinterpret_cast<const char*>(p.W) + (size_t)(KT) * 128;                \
+        char* d_ = smem + (BO) + 2 * G256_HALF + (J) * G256_HALF + wave * 1024;                  \
+        glds16(s_ + ((J) ? boff10 : boff00), d_);                                                \
+        glds16(s_ + ((J) ? boff11 : boff01), d_ + 8192);                                         \
+    }
+// the compute half of a phase; the compiler places counted lgkmcnt waits in front of the MFMAs
+#define G256_COMPUTE(I, J)                                                                       \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                         \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                     \
+                _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                 \
+                    acc[I][mf][J][nf] = mma16<SWAP>(Af[mf][kk], Bf[J][nf][kk], acc[I][mf][J][nf]); \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+
+template <bool SWAP>
+__device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
+                                              acc256_t& acc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- staging addresses: piece (g, tid) of a half-tile = local row g*64 + (tid >> 3), stored
+    // chunk tid & 7, i.e. logical chunk (tid & 7) ^ ((row >> 1) & 7) -------------------------------
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    auto a_off = [&](int i, int g) -> uint32_t {
+        int gm = m0 + g * 128 + i * 64 + srow;
+        gm = gm < p.M ? gm : p.M - 1;   // rows past M read the last row; never stored
+        return (uint32_t)((gm * p.lda + schunk * 8) * 2);
+    };
+    auto b_off = [&](int j, int g) -> uint32_t {
+        const int gn = n0 + (g * 2 + (srow >> 5)) * 64 + j * 32 + (srow & 31);
+        return (uint32_t)((gn * p.ldw + schunk * 8) * 2);
+    };
+    const uint32_t aoff00 = a_off(0, 0), aoff01 = a_off(0, 1), aoff10 = a_off(1, 0), aoff11 = a_off(1, 1);
+    const uint32_t boff00 = b_off(0, 0), boff01 = b_off(0, 1), boff10 = b_off(1, 0), boff11 = b_off(1, 1);
+
+    // ---- fragment read addresses (16x16x32: lane -> row l & 15, k chunk (l >> 4) of the 32-deep half)
+    const int l15 = lane & 15, q = lane >> 4, sw = (lane >> 1) & 7;
+    const uint32_t a_k0 = (uint32_t)((wr * 64 + l15) * 128 + ((q ^ sw) << 4));
+    const uint32_t b_k0 = (uint32_t)(2 * G256_HALF + (wc * 32 + l15) * 128 + ((q ^ sw) << 4));
+    const char* pa0 = smem + a_k0;
+    const char* pa1 = smem + (a_k0 ^ 64);
+    const char* pb0 = smem + b_k0;
+    const char* pb1 = smem + (b_k0 ^ 64);
+
+    bf16x8_t Af[4][2], Bf[2][2][2];
+    const int nk = p.K >> 6;
+
+    // ---- prologue: all of tile 0 and the phase-3/4 half-tiles of tile 1 ---------------------------
+    G256_STAGE_A(0, 0, 0)
+    G256_STAGE_B(0, 0, 0)
+    G256_STAGE_B(1, 0, 0)
+    G256_STAGE_A(1, 0, 0)
+    G256_STAGE_A(0, 1, G256_BUF)
+    G256_STAGE_B(0, 1, G256_BUF)
+    wait_vmcnt<8>();                       // A0(0), B0(0) landed (this thread's pieces)
+    __builtin_amdgcn_s_barrier();          // ... and everybody else's
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave row runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    int bo = 0;   // byte offset of the current tile's buffer
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+        const int bn = bo ^ G256_BUF;
+        G256_READ_B(0) G256_READ_A(0)
+        G256_STAGE_B(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE(0, 0)
+        G256_READ_B(1)
+        G256_STAGE_A(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE(0, 1)
+        G256_READ_A(1)
+        G256_STAGE_A(0, kt + 2, bo)
+        G256_COMPUTE(1, 1)
+        G256_STAGE_B(0, kt + 2, bo)
+        wait_vmcnt<8>();
+        G256_COMPUTE(1, 0)
+        bo = bn;
+        pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);
+        pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
+    }
+    {   // tile nk-2: nothing of tile nk exists
+        const int bn = bo ^ G256_BUF;
+        G256_READ_B(0) G256_READ_A(0)
+        G256_STAGE_B(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE(0, 0)
+        G256_READ_B(1)
+        G256_STAGE_A(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE(0, 1)
+        G256_READ_A(1)
+        G256_COMPUTE(1, 1)
+        wait_vmcnt<4>();                   // A0, B0 of the last tile; its B1, A1 may still fly
+        G256_COMPUTE(1, 0)
+        bo = bn;
+        pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);
+        pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
+    }
+    {   // last tile
+        G256_READ_B(0) G256_READ_A(0)
+        wait_vmcnt<2>();                   // B1
+        G256_COMPUTE(0, 0)
+        G256_READ_B(1)
+        wait_vmcnt<0>();                   // A1
+        G256_COMPUTE(0, 1)
+        G256_READ_A(1)
+        G256_COMPUTE(1, 1)
+        G256_COMPUTE(1, 0)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of wave row 1
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = p.N >> 8;
+    int bid = blockIdx.x;
+    {   // XCD-contiguous tile order (see k_gemm.hip); bijective for any grid size
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int m0 = (bid / tiles_n) << 8;
+    const int n0 = (bid % tiles_n) << 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q = lane >> 4;
+
+    acc256_t acc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) acc[i][mf][j][nf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
+        g256_mainloop<true>(p, smem, m0, n0, acc);
+        // two passes (i = 0, 1) of 128 rows x 256 f32: row lr = wr*64 + mf*16 + l15 of the pass,
+        // 16-B chunk ch of the row stored at ch ^ (lr & 7)
+        const int ch_r = tid & 63, n = n0 + ch_r * 4;
+        f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int lr = wr * 64 + mf * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) {
+                        const int ch = wc * 16 + j * 8 + nf * 4 + q;
+                        *reinterpret_cast<f32x4_t*>(smem + lr * 1024 + ((ch ^ (lr & 7)) << 4)) =
+                            acc[i][mf][j][nf];
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {      // 8 rows per batch: all addend loads first
+                f32x4_t addend[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = (hb * 8 + it) * 8 + wave;
+                    const int m = m0 + (lr >> 6) * 128 + i * 64 + (lr & 63);
+                    const int mc = m < p.M ? m : p.M - 1;
+                    if constexpr (EPI == EPI_RESID)
+                        addend[it] = *reinterpret_cast<const f32x4_t*>(p.Cf + (size_t)mc * p.ldc + n);
+                    else if constexpr (EPI == EPI_F32_POS)
+                        addend[it] = *reinterpret_cast<const f32x4_t*>(
+                            p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n);
+                    else
+                        addend[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = (hb * 8 + it) * 8 + wave;
+                    const int m = m0 + (lr >> 6) * 128 + i * 64 + (lr & 63);
+                    const f32x4_t v =
+                        *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
+                    if (m < p.M)
+                        *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + addend[it];
+                }
+            }
+        }
+    } else {
+        bool v_tile = false;
+        float scale = 1.0f;
+        if constexpr (EPI == EPI_QKV) {
+            v_tile = n0 >= 2 * p.D;
+            scale = (n0 < p.D) ? 0.125f : 1.0f;   // q * 1/sqrt(64), exact in bf16
+        }
+        if (!v_tile) {
+            g256_mainloop<true>(p, smem, m0, n0, acc);
+            // whole tile as [256 rows][512 B]; 8-B chunk c8 of row r stored at c8 ^ ((r & 7) << 1)
+            f32x4_t bias4[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    bias4[j][nf] = *reinterpret_cast<const f32x4_t*>(
+                        p.bias + n0 + wc * 64 + j * 32 + nf * 16 + 4 * q);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int row = wr * 128 + i * 64 + mf * 16 + l15;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const int c8 = wc * 16 + j * 8 + nf * 4 + q;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = acc[i][mf][j][nf][e] + bias4[j][nf][e];
+                                if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);
+                                else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
+                                else v[e] = x * scale;
+                            }
+                            *reinterpret_cast<uint2*>(smem + row * 512 + ((c8 ^ ((row & 7) << 1)) << 3)) =
+                                make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        }
+                }
+            __syncthreads();
+            const int c16 = tid & 31;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (tid >> 5);
+                if (m0 + row < p.M) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c16 ^ (row & 7)) << 4));
+                    bf16_t* dst = (EPI == EPI_QKV)
+                                      ? p.qk + (size_t)(m0 + row) * (2 * p.D) + n0 + c16 * 8
+                                      : p.Cb + (size_t)(m0 + row) * p.ldcb + n0 + c16 * 8;
+                    *reinterpret_cast<uint4*>(dst) = v;
+                }
+            }
+        } else if constexpr (EPI == EPI_QKV) {
+            // V, transposed per head: Vt[b][h][d][t], t contiguous. Lane = d, registers = 4 tokens.
+            g256_mainloop<false>(p, smem, m0, n0, acc);
+            const int heads = p.D >> 6;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    const int drow = wc * 64 + j * 32 + nf * 16 + l15;
+                    const float bias = p.bias[n0 + drow];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf) {
+                            const int c8 = wr * 32 + i * 16 + mf * 4 + q;
+                            const f32x4_t a = acc[i][mf][j][nf];
+                            *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
+                                make_uint2(pack_bf16x2(a[0] + bias, a[1] + bias),
+                                           pack_bf16x2(a[2] + bias, a[3] + bias));
+                        }
+                }
+            __syncthreads();
+            const int c16 = tid & 31;
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 16 + (tid >> 5);
+                const int m = m0 + c16 * 8, nv = n0 + r - 2 * p.D;
+                if (m >= p.M) continue;
+                const int b = m / p.tokens, t = m % p.tokens;
+                bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
+                const char* src = smem + r * 512 + ((c16 ^ (r & 7)) << 4);
+                if (t + 8 <= p.tokens && m + 8 <= p.M && ((t & 7) == 0)) {
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    // the piece straddles a stream boundary (tokens % 8 != 0) or the end of M
+                    for (int e = 0; e < 8 && m + e < p.M; ++e) {
+                        const int me = m + e, be = me / p.tokens, te = me % p.tokens;
+                        p.vt[((size_t)(be * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + te] =
+                            *reinterpret_cast<const bf16_t*>(src + 2 * e);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+hipError_t prepare_one() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+}
+
+template <int EPI>
+hipError_t launch_one(const GemmArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + 255) / 256) * (a.N / 256);
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t gemm256_prepare() {
+    hipError_t e;
+    if ((e = prepare_one<EPI_F32_POS>()) != hipSuccess) return e;
+    if ((e = prepare_one<EPI_RESID>()) != hipSuccess) return e;
+    if ((e = prepare_one<EPI_GELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_one<EPI_RELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_one<EPI_QKV>()) != hipSuccess) return e;
+    return prepare_one<EPI_F32>();
+}
+
+// hipErrorInvalidValue: the shape does not fit this kernel (the caller falls back to k_gemm.hip)
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, hipStream_t st) {
+    if (a.M <= 0 || a.N % 256 != 0 || a.K % 64 != 0 || a.K < 128) return hipErrorInvalidValue;
+    // 32-bit byte offsets from the operand base pointers
+    if ((long long)a.M * a.lda * 2 >= (1ll << 31) || (long long)a.N * a.ldw * 2 >= (1ll << 31))
+        return hipErrorInvalidValue;
+    if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
+    switch (epilogue) {
+        case EPI_F32_POS:
+        case EPI_RESID:
+        case EPI_F32:
+            if ((a.ldc & 3) || !a.Cf) return hipErrorInvalidValue;
+            break;
+        case EPI_GELU_BF16:
+        case EPI_RELU_BF16:
+            if ((a.ldcb & 7) || !a.Cb || !a.bias) return hipErrorInvalidValue;
+            break;
+        case EPI_QKV:
+            if (a.D % 256 != 0 || a.N != 3 * a.D || (a.tokens & 3) ||
+                (a.npad & 3) || !a.bias)
+                return hipErrorInvalidValue;
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    switch (epilogue) {
+        case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, st);
+        case EPI_RESID: return launch_one<EPI_RESID>(a, st);
+        case EPI_GELU_BF16: return launch_one<EPI_GELU_BF16>(a, st);
+        case EPI_RELU_BF16: return launch_one<EPI_RELU_BF16>(a, st);
+        case EPI_QKV: return launch_one<EPI_QKV>(a, st);
+        default: return launch_one<EPI_F32>(a, st);
+    }
+}

@@ -71,6 +71,10 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
 int gemm_pick_config(int M, int N, int K, int epilogue);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
+// k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
+#define GEMM_CFG_256P8 17
+hipError_t gemm256_prepare();
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, hipStream_t st);
 
 // y[r] (bf16) = LN(x[in_row(r)]) ; in_row(r) = (r / group) * in_stride + in_off + r % group
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,

@@ -32,7 +32,7 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
     """each tile configuration (64x64 .. 256x256, ring 2..4) on a ragged M, against float32 NumPy"""
@@ -54,7 +54,7 @@ def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_qkv_every_tile_config(gpu, monkeypatch, cfg):
     monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
     rng = np.random.default_rng(cfg)
@@ -81,6 +81,42 @@ def test_gemm_exact_integers_asymmetric(gpu):
     ref = a @ w.T
     got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), None, epilogue=0)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (256, 512, 256), (1000, 768, 1024)])
+def test_gemm256_exact_integers(gpu, monkeypatch, M, N, K):
+    """the 256x256 8-wave kernel (config 17) on small-integer operands: every product and sum is
+    exact, so any mis-staged half-tile, swizzle slip or early read of a buffer shows as a wrong
+    integer; K = 128 is the shortest supported loop (prologue + the two tail tiles only)"""
+    monkeypatch.setenv("VT_GEMM_CFG", "17")
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
+    ref = a @ w.T + bias
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0), ref)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1),
+                          ref + c0)
+    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3)
+    assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
+
+
+def test_gemm256_long_k_repeatable(gpu, monkeypatch):
+    """config 17 on the fc2 shape of 4 streams (48 K-tiles, 36 workgroups), five launches: the
+    results must agree with float32 NumPy and be bit-identical from launch to launch (a race
+    between the LDS-DMA ring and the fragment reads would show as run-to-run differences)"""
+    monkeypatch.setenv("VT_GEMM_CFG", "17")
+    rng = np.random.default_rng(17)
+    M, N, K = 2880, 768, 3072
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.02)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = a @ w.T + bias
+    first = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0)
+    assert np.abs(first - ref).max() < 2e-3
+    for _ in range(4):
+        assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=0), first)
 
 
 def test_gemm_residual(gpu):
