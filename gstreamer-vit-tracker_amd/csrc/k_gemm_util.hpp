@@ -8,22 +8,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
         (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
-// far below the bf16 rounding of the result): one v_rcp, one v_exp and a degree-5 polynomial
-// instead of libm's erff (~3x the instructions), which made the fc1 epilogue a visible share of
-// the kernel at large tiles.
+// GELU(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|)   (exact identity for both signs).
+// The Gaussian tail is evaluated as Phi(-a) = 2^P(a) with a degree-5 polynomial P fitted to
+// log2(0.5 erfc(a / sqrt 2)) on [0, 9] (weighted so that the error of a * Phi(-a) is minimax): the
+// absolute error of GELU is <= 6.4e-7 for every finite x (float32 evaluation, checked on 2e6
+// points in [-30, 30]; beyond 9 the polynomial keeps falling, so the term underflows to 0 as the
+// true tail does). Cost: 5 fma + v_exp + v_max + fma. The previous form (Abramowitz-Stegun erf:
+// v_rcp + v_exp + 13 more VALU) took 8 us of a 256x256 fc1 tile round of 33 us, because a tile's
+// epilogue is not overlapped with anything when a workgroup owns the whole CU.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    // erf(|x|/sqrt2) = 1 - poly*t*exp(-z^2); exp(-z^2) = 2^(-z^2 log2 e)
-    const float g = poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float erfv = __builtin_copysignf(1.0f - g, x);
-    const float hx = 0.5f * x;
-    return __builtin_fmaf(hx, erfv, hx);
+    const float a = fabsf(x);
+    float p = __builtin_fmaf(-0.0004733149544335902f, a, 0.007084596436470747f);
+    p = __builtin_fmaf(p, a, -0.05182747542858124f);
+    p = __builtin_fmaf(p, a, -0.45999234914779663f);
+    p = __builtin_fmaf(p, a, -1.1507878303527832f);
+    p = __builtin_fmaf(p, a, -1.000037670135498f);
+    return __builtin_fmaf(-a, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
 template <int N>

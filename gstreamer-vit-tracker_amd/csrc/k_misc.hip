@@ -44,10 +44,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Wide variant for D % 256 == 0 (the ViT-B / ViT-L widths): half a wave per row, each lane owns
+// NCH chunks of 8 consecutive floats -> 16-B loads and 16-B bf16 stores (the one-wave-per-row kernel
+// above stores 4 B per lane, 256 B per wave instruction). Same two-pass arithmetic per row; the
+// summation order inside a row differs from the narrow kernel (both are fixed, run-to-run stable).
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             bf16_t* __restrict__ y, int rows, int D,
+                                                             int group, int in_stride, int in_off,
+                                                             float eps) {
+    const int l32 = threadIdx.x & 31;
+    int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = r < rows;
+    r = live ? r : rows - 1;                  // idle half-waves redo the last row, store nothing
+    const size_t in_row = (size_t)(r / group) * in_stride + in_off + (r % group);
+    const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + in_row * D);
+    f32x4_t v[NCH][2];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        v[j][0] = xr[2 * (l32 + 32 * j)];
+        v[j][1] = xr[2 * (l32 + 32 * j) + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += v[j][0][e] + v[j][1][e];
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][h][e] -= mean;
+                sq += v[j][h][e] * v[j][h][e];
+            }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
+    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
+    uint4* yr = reinterpret_cast<uint4*>(y + (size_t)r * D);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = l32 + 32 * j;
+        const f32x4_t g0 = g4[2 * c], g1 = g4[2 * c + 1], b0 = b4[2 * c], b1 = b4[2 * c + 1];
+        uint4 o;
+        o.x = pack_bf16x2((v[j][0][0] * rstd) * g0[0] + b0[0], (v[j][0][1] * rstd) * g0[1] + b0[1]);
+        o.y = pack_bf16x2((v[j][0][2] * rstd) * g0[2] + b0[2], (v[j][0][3] * rstd) * g0[3] + b0[3]);
+        o.z = pack_bf16x2((v[j][1][0] * rstd) * g1[0] + b1[0], (v[j][1][1] * rstd) * g1[1] + b1[1]);
+        o.w = pack_bf16x2((v[j][1][2] * rstd) * g1[2] + b1[2], (v[j][1][3] * rstd) * g1[3] + b1[3]);
+        if (live) yr[c] = o;
+    }
+}
+
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
                             int rows, int D, int group, int in_stride, int in_off, float eps,
                             hipStream_t st) {
     if (rows <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    if (D % 256 == 0 && D / 256 <= 4) {
+        dim3 gridw((rows + 7) / 8), block(256);
+#define LNW_CASE(n)                                                                                \
+    case n:                                                                                        \
+        hipLaunchKernelGGL(layernorm_wide_kernel<n>, gridw, block, 0, st, x, gamma, beta, y, rows, \
+                           D, group, in_stride, in_off, eps);                                      \
+        break;
+        switch (D / 256) { LNW_CASE(1) LNW_CASE(2) LNW_CASE(3) LNW_CASE(4) }
+#undef LNW_CASE
+        return hipGetLastError();
+    }
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(n)                                                                              \
     case n:                                                                                     \
