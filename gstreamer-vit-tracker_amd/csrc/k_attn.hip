@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "vt_common.hpp"
+#include "k_gemm_util.hpp"
 
 __device__ __forceinline__ bf16x8_t ld16(const bf16_t* p) {
     return *reinterpret_cast<const bf16x8_t*>(p);
@@ -49,37 +50,44 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + other_half(v); 
 // lane). Updates the running max / sum, rescales O only when the max moved, and multiplies P into
 // O^T. VALU budget matters here (the tile is 8 MFMAs): exp2 with the log2(e) factor folded into
 // one fma, hardware bf16 packing, and no O rescale while the running max is unchanged.
-#define ATT_LOG2E 1.4426950408889634f
+// Lazy running maximum: m_run is only moved when a score exceeds it by more than ATT_LAZY_LOG2 (in
+// log2 units), so probabilities are at most 2^8 (harmless in bf16 / f32) and the rescale branch -
+// 32 multiplies, and in modes 3/4 also a pass over the scores - is not taken every time one of the
+// wave's 32 queries sees a slightly larger score (with random-like scores that is most steps).
+#define ATT_LAZY_LOG2 8.0f
+
+// Scores arrive in log2 units (the QKV epilogue scales q by log2(e)/8), so p = 2^(s - m).
+// The row sum is taken over the bf16-ROUNDED probabilities, the values the P·V product actually
+// uses (numerator and denominator then round alike; mode 3 gets this sum from an MFMA).
 __device__ __forceinline__ void softmax_pv(f32x16_t s, const bf16x8_t (&vf)[2][2], f32x16_t& o0,
                                            f32x16_t& o1, float& m_run, float& l_run) {
     float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
     for (int r = 4; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
     mx = xhalf_max(mx);
-    if (!__all(mx <= m_run)) {          // some query's max grew: rescale (wave-uniform branch)
+    if (!__all(mx <= m_run + ATT_LAZY_LOG2)) {   // some query's max grew by more than 2^8: rescale (wave-uniform branch)
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * ATT_LOG2E);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         l_run *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
         m_run = m_new;
     }
-    const float mb = -m_run * ATT_LOG2E;
-    float p[16], psum = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], ATT_LOG2E, mb));
-        psum += p[r];
-    }
-    l_run += xhalf_sum(psum);
+    float psum = 0.0f;
     bf16x8_t pf[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         union { uint32_t u[4]; bf16x8_t v; } cv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cv.u[e] = pack_bf16x2(p[8 * s2 + 2 * e], p[8 * s2 + 2 * e + 1]);
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t u = pack_bf16x2(__builtin_amdgcn_exp2f(s[8 * s2 + 2 * e] - m_run),
+                                           __builtin_amdgcn_exp2f(s[8 * s2 + 2 * e + 1] - m_run));
+            psum += __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u);
+            cv.u[e] = u;
+        }
         pf[s2] = cv.v;
     }
+    l_run += xhalf_sum(psum);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s2], pf[s2], o0, 0, 0, 0);
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         float l = 0.0f, sc[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            sc[w] = __expf(mw[w] - m);
+            sc[w] = __builtin_amdgcn_exp2f(mw[w] - m);
             l += s_ml[(w * 2 + 1) * 64 + lane] * sc[w];
         }
         const float inv = 1.0f / l;
@@ -360,31 +368,267 @@ __global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __r
     }
 }
 
-// mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles (many streams),
-// -1 = choose. npad must be a multiple of 64 for mode 2.
+// ---- mode 3: LDS-DMA ring, 64-key steps, permuted Vt ------------------------------------------------
+// Same arithmetic as above (32 queries per wave, S^T = K Q^T, O^T += Vt P^T with the S accumulator
+// as the B operand), restructured around what the PMC counters of mode 2 showed: the kernel is
+// VALU-bound (58 % VALU busy, 22 % MFMA busy, 18.5 VALU instructions per MFMA, about twice what
+// the softmax itself needs). Changes:
+//   * K and Vt tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring with
+//     a counted vmcnt and ONE raw barrier per 64-key step: no staging registers, no ds_write, no
+//     per-step clamping arithmetic.
+//   * Vt is stored by the QKV epilogue with the two middle 4-key runs of every 16 keys swapped
+//     (attn_perm16), so the Vt fragment of a lane - keys {4h..4h+3, 8+4h..8+4h+3} of a 16-key
+//     group, the k-order of an accumulator used as B operand - is ONE ds_read_b128 at chunk
+//     2*s2 + h: K and Vt tiles then have the same LDS image ([64 rows][128 B], chunk c of row r
+//     at c ^ ((r >> 1) & 7)) and share their four per-lane read addresses.
+//   * One softmax per 64 keys: v_max3 reductions, one cross-half exchange and one lazy-rescale
+//     test per step instead of per 32 keys.
+//   * The row sums come from a third P·V MFMA against a tile of ones (the matrix pipe was 28 % busy):
+//     they are the sums of the bf16-rounded probabilities, the values the numerator uses.
+//   * Lazy running maximum with a threshold (ATT_LAZY_LOG2): with 32 queries per wave a slightly
+//     larger score turns up in most steps, so a plain "max grew" test took the rescale branch
+//     almost every step.
+//   Measured and dropped (B = 30, 720 tokens, 12 heads; this kernel 74 us = 650 TFLOP/s, mode 2
+//   103 us): feeding -m_run as the C operand of the first QK MFMA to save the VALU subtraction
+//   (+16 VGPRs -> 2 instead of 3 waves per SIMD: 81 us); an 8-wave variant with the two wave groups
+//   one barrier apart, MFMA phase against softmax phase (110 us: in-kernel stamps gave 1320 cycles
+//   for the 20-MFMA phase beside the partner's 790-cycle softmax phase, plus 2 x 260 cycles in the
+//   barriers); an XCD-contiguous block order alone changed nothing (K/Vt re-reads are L2 hits).
+//   * The output tile is transposed through LDS and stored as whole 128-B rows.
+#define AT3_STAGE 16384
+#define AT3_NS 3
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
+}
+
+__global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __restrict__ qk,
+                                                            const bf16_t* __restrict__ vt,
+                                                            bf16_t* __restrict__ out, int tokens,
+                                                            int H, int npad) {
+    __shared__ __attribute__((aligned(16))) char smem[AT3_NS * AT3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int D = H * 64, ld = 2 * D;
+    const int nqb = (tokens + 31) >> 5, nxb = (nqb + 3) >> 2;
+    // Workgroups are dealt round-robin over the 8 XCDs. The nxb query blocks of one (stream, head)
+    // read the same K and Vt (184 KB at 720 tokens): give each XCD a contiguous run of the 1-D grid
+    // so that they share one L2 instead of pulling the head's K/Vt into six of them (measured
+    // before this remap: the kernel ran at the HBM rate of 6x the K/V bytes).
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int xb = bid % nxb, bh = bid / nxb;
+    const int h = bh % H, b = bh / H;
+    const int qb = xb * 4 + wave;
+
+    const int q = qb * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;     // idle rows repeat the last query, never stored
+    const bf16_t* qrow = qk + ((size_t)b * tokens + qc) * ld + h * 64 + half * 8;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(qrow + ks * 16);
+
+    // staging: LDS position (g, tid) of a tile = row g*32 + (tid >> 3), stored chunk tid & 7, which
+    // holds logical chunk (tid & 7) ^ ((row >> 1) & 7)
+    const int nt = (tokens + 63) >> 6;
+    const int srow = tid >> 3, schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const char* kg = reinterpret_cast<const char*>(qk + (size_t)b * tokens * ld + D + h * 64 + schunk * 8);
+    const char* vg = reinterpret_cast<const char*>(vt + (size_t)(b * H + h) * 64 * npad + schunk * 8);
+    const uint32_t koff0 = (uint32_t)srow * ld * 2, koff1 = (uint32_t)(srow + 32) * ld * 2;
+    const uint32_t voff0 = (uint32_t)srow * npad * 2, voff1 = (uint32_t)(srow + 32) * npad * 2;
+    // the last tile may reach past this stream's keys: clamp its rows (masked below)
+    const int lk0 = (nt - 1) * 64 + srow, lk1 = lk0 + 32;
+    const uint32_t klast0 = (uint32_t)(lk0 < tokens ? lk0 : tokens - 1) * ld * 2;
+    const uint32_t klast1 = (uint32_t)(lk1 < tokens ? lk1 : tokens - 1) * ld * 2;
+#define AT3_STAGE_TILE(KT, SBASE)                                                          \
+    {                                                                                      \
+        const bool last_ = (KT) == nt - 1;                                                 \
+        const char* kp_ = kg + (last_ ? 0 : (size_t)(KT) * 64 * ld * 2);                   \
+        const char* vp_ = vg + (size_t)(KT) * 128;                                         \
+        char* d_ = smem + (SBASE) + wave * 1024;                                           \
+        glds16(kp_ + (last_ ? klast0 : koff0), d_);                                        \
+        glds16(kp_ + (last_ ? klast1 : koff1), d_ + 4096);                                 \
+        glds16(vp_ + voff0, d_ + 8192);                                                    \
+        glds16(vp_ + voff1, d_ + 12288);                                                   \
+    }
+
+    // fragment read addresses inside a stage: row l31 (+32 per tile half / d chunk), chunk
+    // (2*ks + half) ^ sw; the same four serve K (offset st*4096) and Vt (8192 + dc*4096)
+    const int sw = (l31 >> 1) & 7;
+    const uint32_t fa0 = (uint32_t)(l31 * 128 + (((0 + half) ^ sw) << 4));
+    const uint32_t fa1 = (uint32_t)(l31 * 128 + (((2 + half) ^ sw) << 4));
+    const uint32_t fa2 = (uint32_t)(l31 * 128 + (((4 + half) ^ sw) << 4));
+    const uint32_t fa3 = (uint32_t)(l31 * 128 + (((6 + half) ^ sw) << 4));
+
+    // O^T accumulators; osum = ones · P^T: every register of it ends up holding the row sum of the
+    // lane's query (summed over both lane halves by the MFMA itself); only register 0 is used.
+    f32x16_t o0, o1, osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; osum[r] = 0.0f; }
+    float m_run = 0.0f;                  // replaced by the true maximum in the first step
+    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+
+    AT3_STAGE_TILE(0, 0)
+    if (nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
+    int sbase = 0;                       // LDS offset of the stage holding tile kt
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        // every wave's pieces of tile kt have landed, and every wave is done with tile kt-1,
+        // whose stage tile kt+2 overwrites
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nt) {
+            int s2base = sbase + 2 * AT3_STAGE;
+            s2base = s2base >= AT3_NS * AT3_STAGE ? s2base - AT3_NS * AT3_STAGE : s2base;
+            AT3_STAGE_TILE(kt + 2, s2base)
+        }
+        const char* st = smem + sbase;
+        const char* p0 = st + fa0; const char* p1 = st + fa1;
+        const char* p2 = st + fa2; const char* p3 = st + fa3;
+#define AT3_RD(P, OFF) (*reinterpret_cast<const bf16x8_t*>((P) + (OFF)))
+        bf16x8_t kf0[4], kf1[4], vf0[4], vf1[4];
+        kf0[0] = AT3_RD(p0, 0); kf0[1] = AT3_RD(p1, 0); kf0[2] = AT3_RD(p2, 0); kf0[3] = AT3_RD(p3, 0);
+        kf1[0] = AT3_RD(p0, 4096); kf1[1] = AT3_RD(p1, 4096); kf1[2] = AT3_RD(p2, 4096); kf1[3] = AT3_RD(p3, 4096);
+        vf0[0] = AT3_RD(p0, 8192); vf0[1] = AT3_RD(p1, 8192); vf0[2] = AT3_RD(p2, 8192); vf0[3] = AT3_RD(p3, 8192);
+        vf1[0] = AT3_RD(p0, 12288); vf1[1] = AT3_RD(p1, 12288); vf1[2] = AT3_RD(p2, 12288); vf1[3] = AT3_RD(p3, 12288);
+
+        // s = K Q^T - m_run (log2 units): two independent accumulation chains
+        const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                               0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16_t s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
+        f32x16_t s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+        }
+        if (kt == nt - 1 && (tokens & 63) != 0) {      // block-uniform: keys >= tokens -> -inf
+            const int key0 = kt * 64 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2);
+                if (key >= tokens) s0[r] = -INFINITY;
+                if (key + 32 >= tokens) s1[r] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }   // scores relative to the running max
+        // ---- online softmax over the 64 keys of the step (per lane: one query, 32 scores) ----
+        float mx = max3f(s0[0], s0[1], s0[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3f(mx, s0[r], s0[r + 1]);
+        mx = max3f(mx, s0[15], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = max3f(mx, s1[r], s1[r + 1]);
+        mx = fmaxf(mx, s1[15]);
+        mx = xhalf_max(mx);                 // max of (score - m_run) over the query's 64 keys
+        const bool first = kt == 0;         // the first step adopts its maximum whatever its sign
+        if (first || !__all(mx <= ATT_LAZY_LOG2)) {  // else: some query's max grew (wave-uniform branch,
+                                            // rare after the first steps): move to the new max
+            const float dm = first ? mx : fmaxf(mx, 0.0f);          // m_new - m_run, per lane
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);   // O and the sum are 0 in step 0
+            m_run += dm;
+            osum[0] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha; o1[r] *= alpha;
+                s0[r] -= dm; s1[r] -= dm;
+            }
+        }
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            union { uint32_t u[4]; bf16x8_t v; } c0, c1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s0[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s0[8 * g + 2 * e + 1]));
+                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s1[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s1[8 * g + 2 * e + 1]));
+            }
+            pf[g] = c0.v;
+            pf[2 + g] = c1.v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
+            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
+        }
+        sbase = sbase + AT3_STAGE >= AT3_NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
+    }
+    const float l_run = osum[0];
+
+    // ---- epilogue: O^T (d on registers, query on lanes) -> LDS [32 q][128 B] per wave -> rows ----
+    __syncthreads();                      // every wave is done reading the ring
+    {
+        const float inv = 1.0f / l_run;
+        char* ow = smem + wave * 4096;     // 32 rows x 128 B, chunk c of row r at c ^ (r & 7)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // registers 4g..4g+3 hold d = 8g + 4*half + (0..3): 8 B at byte 16g + 8*half (+64 for o1)
+            const uint2 a = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                       pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+            const uint2 c = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                       pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+            *reinterpret_cast<uint2*>(ow + l31 * 128 + ((g ^ (l31 & 7)) << 4) + 8 * half) = a;
+            *reinterpret_cast<uint2*>(ow + l31 * 128 + (((4 + g) ^ (l31 & 7)) << 4) + 8 * half) = c;
+        }
+        // same wave reads back what it wrote (no block barrier needed); 8 lanes per row
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(ow + r * 128 + ((c ^ (r & 7)) << 4));
+            const int qq = qb * 32 + r;
+            if (qb < nqb && qq < tokens)
+                *reinterpret_cast<uint4*>(out + ((size_t)b * tokens + qq) * D + h * 64 + c * 8) = v;
+        }
+    }
+}
+
+// mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
+// 3 = LDS-DMA ring with permuted Vt (default when tokens % 16 == 0 and npad % 64 == 0), -1 = choose.
+int attention_pick_mode(int tokens, int npad) {
+    static const int forced = [] {
+        const char* e = getenv("VT_ATTN_MODE");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced <= 3) return forced;
+    if (npad % 64 != 0) return 0;
+    return (tokens % 16 == 0) ? 3 : 2;
+}
+
+// once per device, outside any stream capture (nothing to raise at present: all LDS is static)
+hipError_t attention_prepare() { return hipSuccess; }
+
 hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                                  int H, int npad, int mode, hipStream_t st) {
     const int nqb = (tokens + 31) / 32;
-    if (mode < 0) mode = (npad % 64 == 0) ? 2 : 0;   // measured: the LDS-shared kernel wins at every batch
-    if (mode == 2 && npad % 64 != 0) return hipErrorInvalidValue;
+    if (mode < 0) mode = attention_pick_mode(tokens, npad);
+    if (mode >= 2 && npad % 64 != 0) return hipErrorInvalidValue;
+    if (mode == 3 && tokens % 16 != 0) return hipErrorInvalidValue;   // a 16-key group must not straddle streams
     if (mode == 0) {
         hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
                            tokens, H, npad);
     } else if (mode == 1) {
         hipLaunchKernelGGL(attention_kernel<false>, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk,
                            vt, out, tokens, H, npad);
-    } else {
+    } else if (mode == 2) {
         hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
+    } else if (mode == 3) {
+        hipLaunchKernelGGL(attention_dma_kernel, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad);
+    } else {
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                             int H, int npad, hipStream_t st) {
-    static const int forced = [] {
-        const char* e = getenv("VT_ATTN_MODE");
-        return e ? atoi(e) : -1;
-    }();
-    return launch_attention_mode(qk, vt, out, B, tokens, H, npad, forced, st);
+    return launch_attention_mode(qk, vt, out, B, tokens, H, npad, attention_pick_mode(tokens, npad), st);
 }

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         float scale = 1.0f;
         if constexpr (EPI == EPI_QKV) {
             v_tile = n0 >= 2 * p.D;
-            scale = (n0 < p.D) ? 0.125f : 1.0f;   // q * 1/sqrt(64), exact in bf16
+            scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;   // q * log2(e)/sqrt(64): scores in log2 units
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
@@ -470,13 +470,16 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int mr = wr * WM + i * 32 + 8 * q + 4 * half;
+                        // permuted Vt layout (attention mode 3): the 4-token run moves inside its
+                        // group of 16 (groups never straddle streams: tokens % 16 == 0 then)
+                        const int mp = p.vt_perm ? attn_perm16(mr) : mr;
                         const uint2 pk = make_uint2(
                             pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
                             pack_bf16x2(acc[i][j][4 * q + 2] + bias, acc[i][j][4 * q + 3] + bias));
                         if constexpr (FITS) {
-                            *reinterpret_cast<uint2*>(smem + nr * STRIDE + mr * 2) = pk;
+                            *reinterpret_cast<uint2*>(smem + nr * STRIDE + mp * 2) = pk;
                         } else if (m0 + mr < p.M) {
-                            const int m = m0 + mr, nv = n0 + nr - 2 * p.D;
+                            const int m = m0 + mp, nv = n0 + nr - 2 * p.D;
                             const int b = m / p.tokens, t = m % p.tokens;
                             bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
                             *reinterpret_cast<uint2*>(dst) = pk;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         float scale = 1.0f;
         if constexpr (EPI == EPI_QKV) {
             v_tile = n0 >= 2 * p.D;
-            scale = (n0 < p.D) ? 0.125f : 1.0f;   // q * 1/sqrt(64), exact in bf16
+            scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;   // q * log2(e)/sqrt(64): scores in log2 units
         }
         if (!v_tile) {
             g256_mainloop<true>(p, smem, m0, n0, acc);
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int mf = 0; mf < 4; ++mf) {
-                            const int c8 = wr * 32 + i * 16 + mf * 4 + q;
+                            // 4-token run q of the 16-token group: runs 1 and 2 swap places in
+                            // the permuted layout (attn_perm16)
+                            const int qp = p.vt_perm ? ((q & 1) << 1 | (q >> 1)) : q;
+                            const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
                             const f32x4_t a = acc[i][mf][j][nf];
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
                                 make_uint2(pack_bf16x2(a[0] + bias, a[1] + bias),

@@ -45,12 +45,16 @@ struct ModelDims {
 
 // ---- kernel launchers (each enqueues on `st`; no allocation, no synchronisation) -------------
 
+// q is stored multiplied by 1/sqrt(64) * log2(e), so that q·k is the softmax exponent in log2 units
+// (the attention kernels use v_exp_f32 = 2^x directly); float(log2 e) / 8 is exact in float32
+#define ATT_Q_SCALE (0.125f * 1.4426950408889634f)
+
 enum GemmEpilogue {
     EPI_F32_POS = 0,   // C f32 = acc + bias + pos[m % pos_rows]      (patch embed)
     EPI_RESID = 1,     // C f32 += acc + bias                          (proj, fc2)
     EPI_GELU_BF16 = 2, // Cb bf16 = gelu(acc + bias)                   (fc1)
     EPI_RELU_BF16 = 3, // Cb bf16 = relu(acc + bias)                   (head convs)
-    EPI_QKV = 4,       // q*0.125,k -> qk[M][2D] bf16; v -> Vt[b][h][64][npad]
+    EPI_QKV = 4,       // q*ATT_Q_SCALE,k -> qk[M][2D] bf16; v -> Vt[b][h][64][npad]
     EPI_F32 = 5        // C f32 = acc + bias                           (operator tests)
 };
 
@@ -63,6 +67,7 @@ struct GemmArgs {
     bf16_t* Cb; int ldcb;         // bf16 output
     const float* pos; int pos_rows;
     bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
+    int vt_perm;                  // Vt key order inside each group of 16: 0 natural, 1 attn_perm16 (attention mode 3)
     unsigned long long* dbg;      // diagnostic builds only (VT_STAMPS): per-wave cycle sums
 };
 
@@ -85,6 +90,15 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                             int H, int npad, hipStream_t st);
 
+// Which attention kernel launch_attention() will run for this shape (env VT_ATTN_MODE overrides),
+// and whether it wants Vt with the permuted key order (mode 3). The QKV GEMM that feeds it must be
+// given the same vt_perm.
+int attention_pick_mode(int tokens, int npad);
+inline int attention_vt_perm(int mode) { return mode == 3 ? 1 : 0; }
+// position of key t inside its group of 16 in the permuted Vt layout: bits 2 and 3 swapped
+__host__ __device__ inline int attn_perm16(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
+
+hipError_t attention_prepare();   // once per device, before the first launch / any stream capture
 hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                                  int H, int npad, int mode, hipStream_t st);
 

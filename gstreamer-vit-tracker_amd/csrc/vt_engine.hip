@@ -376,6 +376,7 @@ int Engine::run_pass(Profiler* prof) {
             a.A = d_ln; a.lda = D; a.W = w.qkv_w; a.ldw = D; a.bias = w.qkv_b;
             a.M = M; a.N = 3 * D; a.K = D;
             a.qk = d_qk; a.vt = d_vt; a.tokens = d.ntok; a.npad = d.npad; a.D = D;
+            a.vt_perm = attention_vt_perm(attention_pick_mode(d.ntok, d.npad));   // layout the attention kernel reads
             gemm(EPI_QKV, a);
         }
         L("attention", 4.0 * B * (double)d.ntok * d.ntok * D, (double)M * D * 8, [&] {
@@ -591,7 +592,7 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
     if (B < 1 || B > 4096) return set_err(VT_ERR_INVALID_ARG, "n_streams %d out of range", B);
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    HIPCHK(gemm_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     Engine* e = new (std::nothrow) Engine();
     if (!e) return set_err(VT_ERR_OOM, "out of host memory");
     e->device = device_id;
@@ -1128,7 +1129,7 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
     if (N % 64 || K % 64) return set_err(VT_ERR_INVALID_ARG, "gemm: N and K must be multiples of 64");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    HIPCHK(gemm_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     DevBuf da, dw, db, dc, dcb;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
     HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
@@ -1170,7 +1171,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     if (M <= 0 || N % 64 || K % 64 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    HIPCHK(gemm_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dc, dcb, dvt;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
@@ -1230,7 +1231,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
-    HIPCHK(gemm_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     const int M = B * tokens, H = D / 64, npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dqk, dvt;
     HIPCHK(da.alloc((size_t)M * D * 2)); HIPCHK(dw.alloc((size_t)3 * D * D * 2)); HIPCHK(db.alloc((size_t)3 * D * 4));
@@ -1242,6 +1243,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = D; g.W = (const bf16_t*)dw.p; g.ldw = D; g.bias = (const float*)db.p;
     g.M = M; g.N = 3 * D; g.K = D; g.qk = (bf16_t*)dqk.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
+    g.vt_perm = (getenv("VT_QKV_PERM") && atoi(getenv("VT_QKV_PERM")) && tokens % 16 == 0) ? 1 : 0;   // tests: the mode-3 attention layout
     HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
     HIPCHK(hipDeviceSynchronize());
     auto widen = [](const DevBuf& d, size_t count, float* out) -> hipError_t {
@@ -1261,24 +1263,25 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
     if (!q || !k || !v || !out || B <= 0 || N <= 0 || H <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
+    HIPCHK(attention_prepare());
     const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
     // host-side packing into the layouts the QKV epilogue produces
+    const char* me = getenv("VT_ATTN_MODE");      // read per call: the tests switch modes
+    const int mode = me ? atoi(me) : attention_pick_mode(N, npad);
+    const bool perm = attention_vt_perm(mode) != 0;
     std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad, 0);
     for (int m = 0; m < M; ++m) {
         memcpy(&qk[(size_t)m * 2 * D], q + (size_t)m * D, (size_t)D * 2);
         memcpy(&qk[(size_t)m * 2 * D + D], k + (size_t)m * D, (size_t)D * 2);
-        const int b = m / N, t = m % N;
+        const int b = m / N, t = m % N, tp = perm ? attn_perm16(t) : t;
         for (int c = 0; c < D; ++c)
-            vt[((size_t)(b * H + c / 64) * 64 + c % 64) * npad + t] = v[(size_t)m * D + c];
+            vt[((size_t)(b * H + c / 64) * 64 + c % 64) * npad + tp] = v[(size_t)m * D + c];
     }
     DevBuf dqk, dvt, dout;
     HIPCHK(dqk.alloc(qk.size() * 2)); HIPCHK(dvt.alloc(vt.size() * 2)); HIPCHK(dout.alloc((size_t)M * D * 2));
     HIPCHK(hipMemcpy(dqk.p, qk.data(), qk.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dvt.p, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
-    {
-        const char* me = getenv("VT_ATTN_MODE");
-        HIPCHK(launch_attention_mode((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, me ? atoi(me) : -1, nullptr));
-    }
+    HIPCHK(launch_attention_mode((const bf16_t*)dqk.p, (const bf16_t*)dvt.p, (bf16_t*)dout.p, B, N, H, npad, mode, nullptr));
     HIPCHK(hipDeviceSynchronize());
     std::vector<bf16_t> tmp((size_t)M * D);
     HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
@@ -1292,6 +1295,7 @@ int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iter
     if (B <= 0 || N <= 0 || H <= 0 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     HIPCHK(hipSetDevice(device_id));
+    HIPCHK(attention_prepare());
     const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
     std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad);
     uint32_t seed = 777u;

@@ -215,17 +215,21 @@ def gelu(x):
             ).astype(np.float32)
 
 
+QK_SCALE = np.float32(0.125 * 1.4426950408889634)   # 1/sqrt(64) * log2(e): float32(log2 e) / 8
+
+
 def attention(q, k, v, heads):
-    """q,k,v [N, H*64] float32 holding bf16 values (q pre-scaled by 1/8) -> [N, H*64] f32"""
-    n = q.shape[0]
+    """q,k,v [N, H*64] float32 holding bf16 values; q pre-scaled by QK_SCALE, so q.k is the softmax
+    exponent in log2 units -> [N, H*64] f32. The probabilities are rounded to bf16 for the P.V
+    product and the row sum is taken over those rounded values (as the HIP kernels do)."""
     out = np.empty_like(q)
     for h in range(heads):
         sl = slice(h * 64, (h + 1) * 64)
         s = q[:, sl] @ k[:, sl].T
         m = s.max(axis=1, keepdims=True)
-        p = np.exp(s - m, dtype=np.float32)
+        p = bf16r(np.exp2((s - m).astype(np.float32)).astype(np.float32))
         l = p.sum(axis=1, keepdims=True, dtype=np.float32)
-        out[:, sl] = (bf16r(p) @ v[:, sl]) / l
+        out[:, sl] = (p @ v[:, sl]) / l
     return out
 
 
@@ -270,7 +274,7 @@ class Model:
             p = f"l{l}."
             h1 = bf16r(layernorm(x, t[p + "ln1_g"], t[p + "ln1_b"], self.eps))
             qkv = (h1 @ t[p + "qkv_w"].T + t[p + "qkv_b"]).astype(np.float32)
-            q = bf16r(qkv[:, :D] * np.float32(0.125))
+            q = bf16r(qkv[:, :D] * QK_SCALE)
             k = bf16r(qkv[:, D:2 * D])
             v = bf16r(qkv[:, 2 * D:])
             o = bf16r(attention(q, k, v, self.H))

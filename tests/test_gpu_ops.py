@@ -8,6 +8,8 @@ from conftest import bf16_round
 
 pytestmark = pytest.mark.gpu
 
+QK_SCALE = np.float32(0.125 * 1.4426950408889634)   # q is stored in log2 units
+
 
 def _bits(vt, x):
     return vt.weights.f32_to_bf16_bits(np.asarray(x, np.float32))
@@ -64,7 +66,7 @@ def test_qkv_every_tile_config(gpu, monkeypatch, cfg):
     bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
     z = a @ w.T + bias
     qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
-    ref_qk = np.concatenate([z[:, :D] * 0.125, z[:, D:2 * D]], axis=1)
+    ref_qk = np.concatenate([z[:, :D] * QK_SCALE, z[:, D:2 * D]], axis=1)
     assert np.all(np.abs(qk - ref_qk) <= np.abs(ref_qk) * 2 ** -8 + 1e-3)
     v = z[:, 2 * D:].reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
     assert np.all(np.abs(vt_[:, :, :tokens] - v) <= np.abs(v) * 2 ** -8 + 1e-3)
@@ -158,7 +160,7 @@ def test_qkv_epilogue_layout(gpu, B, tokens, D):
     bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
     z = a @ w.T + bias
     qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
-    ref_qk = np.concatenate([z[:, :D] * 0.125, z[:, D:2 * D]], axis=1)
+    ref_qk = np.concatenate([z[:, :D] * QK_SCALE, z[:, D:2 * D]], axis=1)
     assert np.all(np.abs(qk - ref_qk) <= np.abs(ref_qk) * 2 ** -8 + 1e-3)
     H = D // 64
     v = z[:, 2 * D:].reshape(B, tokens, H, 64).transpose(0, 2, 3, 1).reshape(B * H, 64, tokens)
@@ -173,7 +175,7 @@ def _attn_ref(q, k, v, B, N, H):
             sl = slice(h * 64, (h + 1) * 64)
             rows = slice(b * N, (b + 1) * N)
             s = q[rows, sl] @ k[rows, sl].T
-            p = np.exp(s - s.max(axis=1, keepdims=True))
+            p = np.exp2(s - s.max(axis=1, keepdims=True))   # q arrives pre-scaled by log2(e)/8
             out[rows, sl] = (p @ v[rows, sl]) / p.sum(axis=1, keepdims=True)
     return out
 
@@ -197,7 +199,47 @@ def test_attention(gpu, monkeypatch, B, N, H, scale, mode):
     assert err.mean() < 2e-3
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
+                                         (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0)])
+def test_attention_mode3(gpu, monkeypatch, B, N, H, scale):
+    """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 16 == 0).
+    Covers a single partial tile (16), a tail of 16 and of 32 keys (80, 720 / 96), full tiles (320),
+    more tiles than ring stages (1008) and a ragged last query block."""
+    monkeypatch.setenv("VT_ATTN_MODE", "3")
+    rng = np.random.default_rng(N + H)
+    D = H * 64
+    qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
+    kb, k = _rand_bf16(gpu, rng, (B * N, D), scale)
+    vb, v = _rand_bf16(gpu, rng, (B * N, D))
+    ref = _attn_ref(q, k, v, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    err = np.abs(got - ref)
+    assert err.max() < 0.02 * max(1.0, np.abs(ref).max()), err.max()
+    assert err.mean() < 2e-3
+    assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H))   # run-to-run identical
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 17])
+def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg):
+    """Vt as attention mode 3 reads it: inside every group of 16 tokens the 4-token runs 1 and 2
+    swap places (position = token with bits 2 and 3 exchanged)"""
+    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
+    monkeypatch.setenv("VT_QKV_PERM", "1")
+    rng = np.random.default_rng(cfg)
+    B, tokens, D = 3, 112, 768
+    ab, a = _rand_bf16(gpu, rng, (B * tokens, D))
+    wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
+    bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
+    z = a @ w.T + bias
+    _, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
+    v = z[:, 2 * D:].reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
+    t = np.arange(tokens)
+    pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    got = vt_[:, :, pos]           # got[..., t] = stored position of token t
+    assert np.all(np.abs(got - v) <= np.abs(v) * 2 ** -8 + 1e-3)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_attention_exact_selector(gpu, monkeypatch, mode):
     monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
