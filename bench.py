@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=24, help="independent tracked streams per GPU")
+    ap.add_argument("--streams", type=int, default=60, help="independent tracked streams per GPU")
     ap.add_argument("--groups", type=int, default=2,
                     help="engines per GPU, each with streams/groups streams on its own HIP stream "
                          "(kernels of different groups overlap on the chip)")

@@ -592,13 +592,14 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
     // 256x256 8-wave kernel (k_gemm256.hip): one workgroup per CU, so it wants the grid to fill
     // the 256 CUs in whole rounds; measured against 128x128 on the tracker's shapes it wins from
     // about half a round upwards unless the last round is nearly empty (profiles/gemm_sweep_r01.txt)
-    if ((N % 256) == 0 && K >= 128 && epilogue != EPI_F32_POS) {
+    if ((N % 256) == 0 && K >= 128) {
         const long t = (long)((M + 255) / 256) * (N / 256), rounds = (t + 255) / 256;
         if (t >= 128 && (rounds == 1 || t * 10 >= rounds * 256 * 6)) return GEMM_CFG_256P8;
     }
     switch (epilogue) {
         case EPI_QKV:
         case EPI_GELU_BF16: return (n128 && tiles128 >= 400) ? 3 : 2;
+        case EPI_RELU_BF16: return (n128 && tiles128 >= 256) ? 3 : 2;   // head convs: N = 256
         case EPI_RESID:
             if (K >= 2048 && M <= 2048) return 0;
             if (K >= 2048 && n128 && tiles128 >= 256) return 3;

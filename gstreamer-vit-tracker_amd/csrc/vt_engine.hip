@@ -80,8 +80,8 @@ const char* g_last_gemm_name = "";  // set by launch_gemm_named below
 
 static const char* gemm_name(int epi, int M, int N, int K) {
     static const char* tags[] = {"f32pos", "resid", "gelu", "relu", "qkv", "f32"};
-    static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s", tags[epi], gemm_config_name(gemm_pick_config(M, N, K, epi)));
+    static thread_local char buf[96];
+    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s_n%dk%d", tags[epi], gemm_config_name(gemm_pick_config(M, N, K, epi)), N, K);
     return buf;
 }
 
