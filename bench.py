@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=60, help="independent tracked streams per GPU")
+    ap.add_argument("--streams", type=int, default=0, help="independent tracked streams per GPU (0: groups x weights.recommended_streams)")
     ap.add_argument("--groups", type=int, default=2,
                     help="engines per GPU, each with streams/groups streams on its own HIP stream "
                          "(kernels of different groups overlap on the chip)")
@@ -89,13 +89,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg_name, wl_text = WORKLOADS[args.workload]
-    B, K, W, R = args.streams, args.steps, args.warmup, args.ring
+    G = args.groups
+    # default: every engine gets the batch that fills the 256 CUs in whole GEMM rounds (30 for cfg3)
+    B = args.streams if args.streams > 0 else G * vt.weights.recommended_streams(cfg_name)
+    K, W, R = args.steps, args.warmup, args.ring
     fw, fh, sq = (3840, 2160, 160) if args.workload == "cfg5" else \
         ((640, 480, 64) if args.workload == "tiny" else (1920, 1080, 64))
 
     # ---- weights: rank 0 generates/reads the blob, RCCL broadcast, every rank builds from HBM ----
     wpath = vt.weights.ensure_weights(cfg_name) if rank == 0 else None
-    G = args.groups
     if B % G:
         raise SystemExit("--streams must be a multiple of --groups")
     Bg = B // G

@@ -91,21 +91,35 @@ __device__ __forceinline__ f32x4_t mma16(const bf16x8_t& xa, const bf16x8_t& wb,
         glds16(s_ + ((J) ? boff10 : boff00), d_);                                                \
         glds16(s_ + ((J) ? boff11 : boff01), d_ + 8192);                                         \
     }
-// the compute half of a phase; the compiler places counted lgkmcnt waits in front of the MFMAs
+// the compute half of a phase; the compiler places counted lgkmcnt waits in front of the MFMAs.
+// G256_T: diagnostic builds (-DVT_STAMPS) accumulate per-wave cycles of the load section, the two
+// barrier waits and the MFMA section; the product build carries no stamps.
+#ifdef VT_STAMPS
+#define G256_T(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define G256_ACC() { st_load += st_b - st_a; st_bar += (st_c - st_b) + (st_e - st_d); st_mfma += st_d - st_c; st_a = st_e; }
+#else
+#define G256_T(v)
+#define G256_ACC()
+#endif
 #define G256_COMPUTE(I, J)                                                                       \
     {                                                                                            \
+        G256_T(st_b)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_barrier();                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        G256_T(st_c)                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                           \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                         \
             _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                     \
                 _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                 \
                     acc[I][mf][J][nf] = mma16<SWAP>(Af[mf][kk], Bf[J][nf][kk], acc[I][mf][J][nf]); \
         __builtin_amdgcn_s_setprio(0);                                                           \
+        G256_T(st_d)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_barrier();                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        G256_T(st_e)                                                                             \
+        G256_ACC()                                                                               \
     }
 
 template <bool SWAP>
@@ -155,6 +169,11 @@ __device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int
     if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave row runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef VT_STAMPS
+    unsigned long long st_a, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_load = 0, st_bar = 0, st_mfma = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    st_a = st_t0;
+#endif
     int bo = 0;   // byte offset of the current tile's buffer
     int kt = 0;
     for (; kt < nk - 2; ++kt) {
@@ -206,6 +225,12 @@ __device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int
         G256_COMPUTE(1, 1)
         G256_COMPUTE(1, 0)
     }
+#ifdef VT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = st_bar; d[1] = st_load; d[2] = st_mfma; d[3] = __builtin_amdgcn_s_memtime() - st_t0;
+    }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of wave row 1
     __builtin_amdgcn_sched_barrier(0);
 }

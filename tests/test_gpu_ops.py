@@ -104,6 +104,24 @@ def test_gemm256_exact_integers(gpu, monkeypatch, M, N, K):
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
+def test_gemm256_full_chip_exact_integers(gpu, monkeypatch):
+    """config 17 at the bench's size (30 streams: M = 21,600, fc1 shape, 1020 workgroups = 4 rounds
+    on 256 CUs) with small-integer operands: every output must be the exact integer, three launches
+    in a row. A half-tile read before its LDS-DMA landed, or overwritten while still being read,
+    only shows under full-chip memory load - this is the case the small shapes cannot reach."""
+    monkeypatch.setenv("VT_GEMM_CFG", "17")
+    rng = np.random.default_rng(2026)
+    M, N, K = 21600, 3072, 768
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    ref = a @ w.T + bias          # |sums| <= 12,296: exact in float32 in any order
+    ab, wb = _bits(gpu, a), _bits(gpu, w)
+    for _ in range(3):
+        got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0)
+        assert np.array_equal(got, ref)
+
+
 def test_gemm256_long_k_repeatable(gpu, monkeypatch):
     """config 17 on the fc2 shape of 4 streams (48 K-tiles, 36 workgroups), five launches: the
     results must agree with float32 NumPy and be bit-identical from launch to launch (a race

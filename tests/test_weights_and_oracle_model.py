@@ -103,3 +103,16 @@ def test_oracle_preproc_properties(vt, oracle):
                                                 nb))
     for c in range(3):
         assert np.all(pm[:, c * 256:(c + 1) * 256] == oracle.bf16r(nb[c]))
+
+
+def test_recommended_streams_fill_whole_gemm_rounds(vt):
+    """the batch per engine pass is chosen so that the 256x256 GEMM kernel's grids are whole rounds
+    of the 256 CUs: ViT-B/16 t192/s384 -> 30 streams = 85 row tiles -> 255 / 765 / 1020 tiles"""
+    assert vt.weights.recommended_streams("cfg3") == 30
+    cfg = vt.weights.get_config("cfg3")
+    rows = -(-30 * (cfg.n_t + cfg.n_s) // 256)
+    assert [rows * c for c in (3, 9, 12)] == [255, 765, 1020]
+    assert vt.weights.recommended_streams("tiny") == 1      # D = 128: the 256-wide kernel never applies
+    for name in ("cfg2", "cfg5"):
+        b = vt.weights.recommended_streams(name)
+        assert 1 < b <= 128
