@@ -83,7 +83,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_group_update_device", "vt_group_hip_stream", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
@@ -139,6 +139,8 @@ def lib():
     L.vt_group_enqueue_device.argtypes = [c_void_p, POINTER(CFrame), c_int]
     L.vt_group_wait.argtypes = [c_void_p, POINTER(CResult), c_int]
     L.vt_group_update_device.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
+    L.vt_group_init_host.argtypes = [c_void_p, c_int, POINTER(CFrame), CBBox]
+    L.vt_group_update_host.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
     L.vt_group_hip_stream.argtypes = [c_void_p]
     L.vt_group_hip_stream.restype = c_void_p
     L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
@@ -416,6 +418,34 @@ class Group:
         arr = self._arr(frames)
         out = (CResult * len(frames))()
         _check(lib().vt_group_update_device(self._h, arr, len(frames), out))
+        return [TrackResult(r) for r in out]
+
+    @staticmethod
+    def _host_frame(frame):
+        """(CFrame with HOST pointers, keep-alive object) for an (H,W,3) RGB array, NV12Frame or
+        YUY2Frame"""
+        if isinstance(frame, NV12Frame):
+            uv = frame.buf[frame.w * frame.h:]
+            return CFrame(frame.buf.ctypes.data, uv.ctypes.data, frame.w, frame.h, frame.w,
+                          (frame.w + 1) & ~1, PIX_NV12, 0, 0, 0), frame
+        if isinstance(frame, YUY2Frame):
+            return CFrame(frame.buf.ctypes.data, None, frame.w, frame.h, 2 * frame.w, 0, PIX_YUY2,
+                          0, 0, 0), frame
+        a = np.ascontiguousarray(frame, np.uint8)
+        h, w, _ = a.shape
+        return CFrame(a.ctypes.data, None, w, h, 3 * w, 0, PIX_RGB8, 0, 0, 0), a
+
+    def init_host(self, stream: int, frame, bbox: BBox):
+        f, keep = self._host_frame(frame)
+        _check(lib().vt_group_init_host(self._h, stream, byref(f), bbox._c()))
+
+    def update_host(self, frames):
+        """one pass on HOST frames (RGB arrays / NV12Frame / YUY2Frame, one per stream): only the
+        search windows cross PCIe, in one copy"""
+        pairs = [self._host_frame(fr) for fr in frames]
+        arr = (CFrame * len(pairs))(*[p[0] for p in pairs])
+        out = (CResult * len(pairs))()
+        _check(lib().vt_group_update_host(self._h, arr, len(pairs), out))
         return [TrackResult(r) for r in out]
 
     def profile_device(self, frames, iters=5):

@@ -714,6 +714,37 @@ int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result
 }
 void* vt_group_hip_stream(vt_group* g) { return g ? (void*)g->e->stream : nullptr; }
 
+static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float (*boxes)[4], vt_frame* dev);
+
+int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box) {
+    if (!g || !host_frame) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));     // the staging arena is shared by the group's passes
+    const float fb[1][4] = {{(float)box.x, (float)box.y, (float)box.width, (float)box.height}};
+    vt_frame f;
+    if (int rc = stage_host_frames(e, host_frame, 1, fb, &f)) return rc;
+    return e->init_stream(stream, &f, box);
+}
+
+int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out) {
+    if (!g || !host_frames || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "update_host: need exactly %d frames", e->B);
+    for (int b = 0; b < n; ++b)
+        if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));     // last pass done: its boxes are in h_states_all
+    std::vector<vt_frame> dev((size_t)n);
+    std::vector<float> boxes((size_t)n * 4);
+    for (int b = 0; b < n; ++b) memcpy(&boxes[(size_t)b * 4], e->h_states_all[b].box, 4 * sizeof(float));
+    if (int rc = stage_host_frames(e, host_frames, n, reinterpret_cast<const float(*)[4]>(boxes.data()), dev.data()))
+        return rc;
+    if (int rc = e->enqueue(dev.data(), n)) return rc;
+    return e->wait(out, n);
+}
+
 int vt_group_enable_taps(vt_group* g, int enable) {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     Engine* e = g->e;
@@ -861,8 +892,20 @@ int vt_get_model_info(const vt_tracker* t, vt_model_info* out) {
 // the tracker reads a window of side 4*sqrt(w*h) around the last box; that window is packed into a
 // pinned buffer on the host (a few hundred KB) and copied asynchronously ahead of the kernels.
 // The caller's buffer is no longer referenced when this returns (src/pipeline.rs:125 draws into it).
-static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
-                            int s0, int s1, const float* box, vt_frame* f) {
+// ---- host-frame ingest: only the windows that the pass can sample cross PCIe ----------------------
+// The reference hands over whole frames (6.2 MB of RGB8 at 1080p, src/pipeline.rs:105-112) although
+// the tracker reads a window of side 4*sqrt(w*h) around the last box. The windows of all the frames
+// of a call are packed back to back into one pinned arena and moved with ONE async H2D copy; the
+// frame descriptors handed to the kernels point into the device copy and carry the window origin.
+struct HostWin {
+    int fmt, w, h, s0, s1;
+    const uint8_t *p0, *p1;
+    int x_lo, y_lo, ww, wh;
+    size_t bytes, uv_off;
+};
+
+static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
+                       int s0, int s1, const float* box, HostWin* win) {
     if (!p0 || w < 16 || h < 16) return set_err(VT_ERR_INVALID_ARG, "null frame or size < 16");
     if (w > e->max_w || h > e->max_h)
         return set_err(VT_ERR_INVALID_ARG, "frame %dx%d exceeds configured max %dx%d", w, h, e->max_w, e->max_h);
@@ -870,15 +913,10 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
         if (s0 < 3 * w) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
     } else if (fmt == VT_PIX_YUY2) {
         if ((w & 1) || s0 < 2 * w) return set_err(VT_ERR_INVALID_ARG, "yuy2: odd width or stride < 2*width");
-    } else if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) {
-        return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
-    }
-    HIPCHK(hipSetDevice(e->device));
-    const size_t need = (size_t)e->max_w * e->max_h * 3 + 4096;
-    if (!e->d_stage) {
-        HIPCHK(hipMalloc((void**)&e->d_stage, need));
-        HIPCHK(hipHostMalloc((void**)&e->h_pack, need));
-        e->stage_bytes = need;
+    } else if (fmt == VT_PIX_NV12) {
+        if (!p1 || s0 < w || s1 < ((w + 1) & ~1)) return set_err(VT_ERR_INVALID_ARG, "nv12: bad plane or stride");
+    } else {
+        return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", fmt);
     }
     // window = search crop (factor 4; it contains the factor-2 template crop) + bilinear margin
     const float side = 4.0f * sqrtf(fmaxf(box[2] * box[3], 1.0f));
@@ -892,33 +930,94 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
     if (x_hi - x_lo < 2 || y_hi - y_lo < 2) {   // window misses the frame: nothing can be sampled
         x_lo = 0; y_lo = 0; x_hi = 2; y_hi = 2;
     }
-    const int ww = (int)(x_hi - x_lo), wh = (int)(y_hi - y_lo);
-    memset(f, 0, sizeof(*f));
-    f->width = w; f->height = h; f->format = fmt;
-    f->origin_x = (int)x_lo; f->origin_y = (int)y_lo;
-    f->reserved = 1;   // strides describe the packed window
-    size_t bytes;
-    if (fmt == VT_PIX_RGB8 || fmt == VT_PIX_YUY2) {
-        const size_t bpp = fmt == VT_PIX_RGB8 ? 3 : 2;
-        const size_t rb = (size_t)ww * bpp;
-        for (int r = 0; r < wh; ++r)
-            memcpy(e->h_pack + r * rb, p0 + (size_t)(y_lo + r) * s0 + (size_t)x_lo * bpp, rb);
-        bytes = rb * wh;
-        f->plane0 = e->d_stage; f->stride0 = (int)rb;
+    win->fmt = fmt; win->w = w; win->h = h; win->s0 = s0; win->s1 = s1; win->p0 = p0; win->p1 = p1;
+    win->x_lo = (int)x_lo; win->y_lo = (int)y_lo;
+    win->ww = (int)(x_hi - x_lo); win->wh = (int)(y_hi - y_lo);
+    if (fmt == VT_PIX_NV12) {
+        const int uvw = (win->ww + 1) & ~1, uvh = (win->wh + 1) / 2;
+        win->uv_off = ((size_t)win->ww * win->wh + 255) & ~(size_t)255;
+        win->bytes = win->uv_off + (size_t)uvw * uvh;
     } else {
-        const int uvw = (ww + 1) & ~1, uvh = (wh + 1) / 2;
-        for (int r = 0; r < wh; ++r)
-            memcpy(e->h_pack + (size_t)r * ww, p0 + (size_t)(y_lo + r) * s0 + x_lo, (size_t)ww);
-        const size_t uv_off = ((size_t)ww * wh + 255) & ~(size_t)255;
-        // odd frame width: the last pixel's V byte lies one past the row's last full pair
-        const int uv_avail = std::min<long>(uvw, (long)s1 - x_lo);
-        for (int r = 0; r < uvh; ++r)
-            memcpy(e->h_pack + uv_off + (size_t)r * uvw, p1 + (size_t)(y_lo / 2 + r) * s1 + x_lo, (size_t)uv_avail);
-        bytes = uv_off + (size_t)uvw * uvh;
-        f->plane0 = e->d_stage; f->plane1 = e->d_stage + uv_off; f->stride0 = ww; f->stride1 = uvw;
+        win->uv_off = 0;
+        win->bytes = (size_t)win->ww * win->wh * (fmt == VT_PIX_RGB8 ? 3 : 2);
     }
-    HIPCHK(hipMemcpyAsync(e->d_stage, e->h_pack, bytes, hipMemcpyHostToDevice, e->stream));
+    win->bytes = (win->bytes + 255) & ~(size_t)255;
     return VT_OK;
+}
+
+// pinned + device arena of at least `need` bytes (grown with the stream idle)
+static int ensure_stage(Engine* e, size_t need) {
+    if (need <= e->stage_bytes) return VT_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->d_stage) { (void)hipFree(e->d_stage); e->d_stage = nullptr; }
+    if (e->h_pack) { (void)hipHostFree(e->h_pack); e->h_pack = nullptr; }
+    e->stage_bytes = 0;
+    const size_t cap = need + need / 2 + 4096;
+    HIPCHK(hipMalloc((void**)&e->d_stage, cap));
+    HIPCHK(hipHostMalloc((void**)&e->h_pack, cap));
+    e->stage_bytes = cap;
+    return VT_OK;
+}
+
+static void pack_window(Engine* e, const HostWin& wn, size_t off, vt_frame* f) {
+    uint8_t* dst = e->h_pack + off;
+    memset(f, 0, sizeof(*f));
+    f->width = wn.w; f->height = wn.h; f->format = wn.fmt;
+    f->origin_x = wn.x_lo; f->origin_y = wn.y_lo;
+    f->reserved = 1;   // strides describe the packed window
+    if (wn.fmt == VT_PIX_RGB8 || wn.fmt == VT_PIX_YUY2) {
+        const size_t bpp = wn.fmt == VT_PIX_RGB8 ? 3 : 2;
+        const size_t rb = (size_t)wn.ww * bpp;
+        for (int r = 0; r < wn.wh; ++r)
+            memcpy(dst + r * rb, wn.p0 + (size_t)(wn.y_lo + r) * wn.s0 + (size_t)wn.x_lo * bpp, rb);
+        f->plane0 = e->d_stage + off; f->stride0 = (int)rb;
+    } else {
+        const int uvw = (wn.ww + 1) & ~1, uvh = (wn.wh + 1) / 2;
+        for (int r = 0; r < wn.wh; ++r)
+            memcpy(dst + (size_t)r * wn.ww, wn.p0 + (size_t)(wn.y_lo + r) * wn.s0 + wn.x_lo, (size_t)wn.ww);
+        // odd frame width: the last pixel's V byte lies one past the row's last full pair
+        const int uv_avail = (int)std::min<long>(uvw, (long)wn.s1 - wn.x_lo);
+        for (int r = 0; r < uvh; ++r)
+            memcpy(dst + wn.uv_off + (size_t)r * uvw, wn.p1 + (size_t)(wn.y_lo / 2 + r) * wn.s1 + wn.x_lo,
+                   (size_t)uv_avail);
+        f->plane0 = e->d_stage + off; f->plane1 = e->d_stage + off + wn.uv_off;
+        f->stride0 = wn.ww; f->stride1 = uvw;
+    }
+}
+
+// n host frames -> n device frame descriptors (windows packed, one H2D copy enqueued on the stream).
+// boxes[i]: the box that decides stream i's window (the new box at init, the last state at update).
+static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float (*boxes)[4], vt_frame* dev) {
+    std::vector<HostWin> wins((size_t)n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const vt_frame& hf = host[i];
+        if (int rc = plan_window(e, hf.format, (const uint8_t*)hf.plane0, (const uint8_t*)hf.plane1, hf.width,
+                                 hf.height, hf.stride0, hf.stride1, boxes[i], &wins[i]))
+            return rc;
+        total += wins[i].bytes;
+    }
+    if (int rc = ensure_stage(e, total)) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    // the previous call's copy out of the pinned arena has finished: every host entry point waits
+    // for its pass before returning
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        pack_window(e, wins[i], off, &dev[i]);
+        off += wins[i].bytes;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_stage, e->h_pack, total, hipMemcpyHostToDevice, e->stream));
+    return VT_OK;
+}
+
+static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
+                            int s0, int s1, const float* box, vt_frame* f) {
+    vt_frame hf;
+    memset(&hf, 0, sizeof(hf));
+    hf.plane0 = p0; hf.plane1 = p1; hf.width = w; hf.height = h; hf.stride0 = s0; hf.stride1 = s1; hf.format = fmt;
+    float b4[1][4] = {{box[0], box[1], box[2], box[3]}};
+    return stage_host_frames(e, &hf, 1, b4, f);
 }
 
 static int do_init(vt_tracker* t, const vt_frame* f, vt_bbox box) { return t->e->init_stream(0, f, box); }

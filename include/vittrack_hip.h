@@ -174,6 +174,13 @@ int vt_group_wait(vt_group* g, vt_result* out, int n);
 int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out);
 /* HIP stream the group launches on (hipStream_t as void*), for event timing by the caller */
 void* vt_group_hip_stream(vt_group* g);
+/* The same with HOST frames (vt_frame.plane0/plane1 are host addresses; any pixel format, strides
+ * honoured, origin fields ignored): ≙ B reference hosts calling tracker.init / tracker.update
+ * (src/tracker_context.rs:88,90,120) in the same frame period. Only each stream's search window is
+ * read from the caller's buffers; the windows of all n frames are packed into one pinned arena and
+ * cross PCIe in one copy. Synchronous: the caller's buffers may be reused on return. */
+int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box);
+int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out);
 
 /* ---- reference colour converter on the GPU ---------------------------------------------- */
 

@@ -261,6 +261,52 @@ def test_batched_30_streams_cfg3_large_tile_path(gpu, oracle, weights_cfg3):
             assert d <= 1 and abs(res[i].score - r.score) < 0.03, (t, i, res[i], r)
 
 
+def test_group_host_frames_equal_device_frames(gpu, weights_tiny):
+    """vt_group_update_host: B host frames of mixed pixel formats in one call (windows packed into
+    one pinned arena, one H2D copy) give exactly what the same frames resident in HBM give."""
+    import torch
+    B, w, h = 4, 640, 480
+    scs = [gpu.synth.MovingSquare(w, h, 64, seed=40 + i) for i in range(B)]
+    g_host = gpu.Group(weights_tiny, n_streams=B)
+    g_dev = gpu.Group(weights_tiny, n_streams=B)
+
+    def host_frame(i, t):     # streams 0, 2: NV12; 1: RGB8; 3: YUY2 made from the same scene
+        if i == 1:
+            return scs[i].frame_rgb8(t)
+        if i == 3:
+            return gpu.YUY2Frame(scs[i].frame_yuy2(t), w, h) if hasattr(scs[i], "frame_yuy2") else \
+                gpu.NV12Frame(scs[i].frame_nv12(t), w, h)
+        return gpu.NV12Frame(scs[i].frame_nv12(t), w, h)
+
+    for t in range(6):
+        hf = [host_frame(i, t) for i in range(B)]
+        keep, dframes = [], []
+        for i, f in enumerate(hf):
+            if isinstance(f, gpu.NV12Frame):
+                d = torch.from_numpy(f.buf).cuda()
+                dframes.append(gpu.frame_nv12(d.data_ptr(), d.data_ptr() + w * h, w, h))
+            elif isinstance(f, gpu.YUY2Frame):
+                d = torch.from_numpy(f.buf).cuda()
+                dframes.append(gpu.CFrame(d.data_ptr(), None, w, h, 2 * w, 0, gpu.PIX_YUY2, 0, 0, 0))
+            else:
+                d = torch.from_numpy(np.ascontiguousarray(f)).cuda()
+                dframes.append(gpu.frame_rgb8(d.data_ptr(), w, h))
+            keep.append(d)
+        if t == 0:
+            for i in range(B):
+                box = gpu.BBox.new(*scs[i].gt_box(0))
+                g_host.init_host(i, hf[i], box)
+                g_dev.init_device(i, dframes[i], box)
+        rh = g_host.update_host(hf)
+        rd = g_dev.update_device(dframes)
+        for i in range(B):
+            assert rh[i].bbox == rd[i].bbox and rh[i].success == rd[i].success
+            assert abs(rh[i].score - rd[i].score) < 1e-6
+            assert rh[i].success
+    with pytest.raises(gpu.VtError):
+        g_host.update_host(hf[:2])          # a pass needs one frame per stream
+
+
 def test_errors_do_not_abort(gpu, weights_tiny, tmp_path):
     with pytest.raises(gpu.VtError):
         gpu.VitTrack.new(str(tmp_path / "missing.vtw"))
