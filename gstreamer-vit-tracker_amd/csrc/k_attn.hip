@@ -393,7 +393,13 @@ __global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __r
 //   (+16 VGPRs -> 2 instead of 3 waves per SIMD: 81 us); an 8-wave variant with the two wave groups
 //   one barrier apart, MFMA phase against softmax phase (110 us: in-kernel stamps gave 1320 cycles
 //   for the 20-MFMA phase beside the partner's 790-cycle softmax phase, plus 2 x 260 cycles in the
-//   barriers); an XCD-contiguous block order alone changed nothing (K/Vt re-reads are L2 hits).
+//   barriers); an XCD-contiguous block order alone changed nothing (K/Vt re-reads are L2 hits);
+//   software-pipelining the step inside the wave (QK of step kt+1 and P·V of step kt-1 issued
+//   among the softmax VALU of step kt, two register sets, 250 VGPRs -> 2 waves per SIMD: 84 us).
+//   In-kernel stamps of this kernel, cycles per 64-key step and wave (3,530 in all): vmcnt + barrier
+//   276; LDS-DMA issue + 16 ds_read + QK (behind the previous step's P·V still in the pipe) + max
+//   1,920; 2^x + pack 607; P·V issue 418 - a wave's step is latency, not issue, and three waves per
+//   SIMD hide about two thirds of it.
 //   * The output tile is transposed through LDS and stored as whole 128-B rows.
 #define AT3_STAGE 16384
 #define AT3_NS 3

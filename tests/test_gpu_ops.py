@@ -237,6 +237,27 @@ def test_attention_mode3(gpu, monkeypatch, B, N, H, scale):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H))   # run-to-run identical
 
 
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
+    """scores that grow by far more than the lazy-max threshold (2^8) late in the key sequence:
+    the running maximum must move and everything accumulated before be rescaled"""
+    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
+    rng = np.random.default_rng(77)
+    B, N, H = 1, 320, 2
+    D = H * 64
+    qb, q = _rand_bf16(gpu, rng, (N, D), 0.35)
+    k = (rng.standard_normal((N, D)) * 1.0).astype(np.float32)
+    ramp = 1.0 + 12.0 * (np.arange(N) // 64)[:, None]          # key tiles 0..4: scale 1, 13, 25, 37, 49
+    kb = _bits(gpu, k * ramp)
+    k = gpu.weights.bf16_bits_to_f32(kb)
+    vb, v = _rand_bf16(gpu, rng, (N, D))
+    ref = _attn_ref(q, k, v, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    err = np.abs(got - ref)
+    assert np.isfinite(got).all()
+    assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
+
+
 @pytest.mark.parametrize("cfg", [2, 3, 17])
 def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg):
     """Vt as attention mode 3 reads it: inside every group of 16 tokens the 4-token runs 1 and 2

@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0, '.')
 import gstreamer_vit_tracker_amd as vt
-modes = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2]
+modes = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3]
 Bs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 8, 16, 32]
 N, H = 720, 12
 for B in Bs:
