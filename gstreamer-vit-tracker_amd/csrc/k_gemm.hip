@@ -29,26 +29,18 @@
 #define GEMM_BK 64
 #define ROW_BYTES 128
 
-// The NS template parameter encodes the staging scheme:
-//   2..4     LDS-DMA ring of NS stages, K-tile depth 64 (128-B LDS rows)
-//   32 + d   LDS-DMA ring of d stages, K-tile depth 32 (64-B LDS rows): half the bytes per stage, so
-//            more stages in flight fit next to a second block on the CU
-//   -2       register-staged double buffer, depth 64
-__host__ __device__ constexpr int ring_depth(int ns) { return ns < 0 ? -ns : (ns >= 32 ? ns - 32 : ns); }
-__host__ __device__ constexpr int tile_bk(int ns) { return ns >= 32 ? 32 : 64; }
-__host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn) {
-    return ring_depth(ns) * (bm + bn) * tile_bk(ns) * 2;
-}
+// LDS ring: NS stages of (BM + BN) rows x 128 B (K-tile depth 64)
+__host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn) { return ns * (bm + bn) * GEMM_BK * 2; }
 
 // accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile
 __device__ __forceinline__ int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
-template <int BM, int BN, int WVM, int WVN, int NSX, bool ROW_ON_LANE>
+template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                               f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
-    constexpr int NS = ring_depth(NSX), BK = tile_bk(NSX);
+    constexpr int BK = GEMM_BK;
     constexpr int ROWB = BK * 2;                // bytes per LDS row
     constexpr int CPR = BK / 8;                 // 16-B chunks per row (8 or 4)
     constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB LDS-DMA piece (8 or 16)
@@ -58,9 +50,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     constexpr int PA = BM / (RPP * NW), PB = BN / (RPP * NW);  // 1-KiB LDS-DMA pieces per wave
     static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     constexpr int STAGE = (BM + BN) * ROWB;
-    // chunk swizzle: 128-B rows c ^ ((r >> 1) & 7); 64-B rows c ^ ((r >> 2) & 3) — both make the
-    // ds_read_b128 of a 32-row MFMA operand hit 16 distinct 16-B slots per lane group
-    auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    // chunk swizzle c ^ ((r >> 1) & 7): the ds_read_b128 of a 32-row MFMA operand hits 16 distinct
+    // 16-B slots per lane group
+    auto swz = [](int row) { return (row >> 1) & 7; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WVN, wc = wave % WVN;
     const int l31 = lane & 31, half = lane >> 5;
@@ -146,11 +138,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         STAMP(st_a) st_issue += st_a - st_b;
 #endif
         const char* sbase = smem + cur * STAGE;
-#if defined(VT_ABLATE) && VT_ABLATE == 3     /* 3: loads and barriers only */
-        asm volatile("" ::"v"(sbase));
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        continue;
-#endif
         // k-steps software-pipelined inside the wave: the fragments of step ks+1 are read from LDS
         // while the MFMAs of step ks issue (the compiler then waits with a counted lgkmcnt instead
         // of draining every read before every MFMA group)
@@ -179,25 +166,19 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-#if defined(VT_ABLATE) && VT_ABLATE == 2     /* 2: LDS reads but no MFMA */
-                    asm volatile("" ::"v"(af[cb][i]), "v"(bfr[cb][j]));
-#else
                     if (ROW_ON_LANE)  // D[n][m]: lane = m (row of C), registers = n
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][j], af[cb][i],
                                                                             acc[i][j], 0, 0, 0);
                     else              // D[m][n]: lane = n (column of C), registers = m
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][i], bfr[cb][j],
                                                                             acc[i][j], 0, 0, 0);
-#endif
                 }
-#if !defined(VT_ABLATE) || VT_ABLATE != 1   /* 1: no operand loads after the prologue */
             if (prefetch) {
                 constexpr int Q0 = 0;  // pieces [ks*IPS/KS, (ks+1)*IPS/KS) go with k-step ks
 #pragma unroll
                 for (int q = Q0 + ks * IPS / KS; q < (ks + 1) * IPS / KS; ++q)
                     issue_piece(pf_kt, pf_buf, q);
             }
-#endif
         }
 #ifdef VT_STAMPS
         STAMP(st_b) st_comp += st_b - st_a;
@@ -210,124 +191,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         d[0] = st_wait; d[1] = st_issue; d[2] = st_comp; d[3] = clock64() - st_t0;
     }
 #endif
-}
-
-// Register-staged variant of the main loop (two LDS buffers): the global loads of K-tile t+1 are
-// issued as ordinary 16-B loads into registers BEFORE tile t is computed and written to the other
-// LDS buffer after it (one barrier per tile). Same LDS image and fragment reads as the LDS-DMA
-// loop. Why it exists: one global_load_lds costs the issuing wave ~60-180 cycles of issue time; at
-// 8 pieces per wave per K-tile that is more than the 512 MFMA cycles of the tile itself, whereas a
-// global_load_dwordx4 + ds_write_b128 pair costs ~20.
-template <int BM, int BN, int WVM, int WVN, bool ROW_ON_LANE>
-__device__ __forceinline__ void gemm_mainloop_rs(const GemmArgs& p, char* smem, int m0, int n0,
-                                                 f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
-    constexpr int NT = WVM * WVN * 64;
-    constexpr int WM = BM / WVM, WN = BN / WVN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-B chunks per thread per tile
-    static_assert(CA >= 1 && CB >= 1, "tile too small");
-    constexpr int STAGE = (BM + BN) * ROW_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WVN, wc = wave % WVN;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    // chunk c = tid + NT*j of a tile: row c >> 3, 16-B piece c & 7 (recomputed where used: arrays
-    // of per-chunk pointers/registers would be left in scratch memory by the compiler)
-    typedef uint32_t rega_t __attribute__((ext_vector_type(4 * CA)));
-    typedef uint32_t regb_t __attribute__((ext_vector_type(4 * CB)));
-    const int row0 = tid >> 3, ch0 = tid & 7;           // chunk j: row0 + j*NT/8, same piece
-    const int swz_dst0 = row0 * ROW_BYTES;
-    int aoff[TM], boff[TN], aswz[TM], bswz[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wr * WM + i * 32 + l31;
-        aoff[i] = row * ROW_BYTES;
-        aswz[i] = (row >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wc * WN + j * 32 + l31;
-        boff[j] = BM * ROW_BYTES + row * ROW_BYTES;
-        bswz[j] = (row >> 1) & 7;
-    }
-
-    const int nk = p.K / GEMM_BK;
-    rega_t ra;
-    regb_t rb;
-    (void)swz_dst0;
-#define RS_LOAD(KT)                                                                              \
-    {                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < CA; ++j) {                                         \
-            const int row = row0 + j * (NT / 8);                                                 \
-            int gm = m0 + row;                                                                   \
-            gm = gm < p.M ? gm : p.M - 1;                                                        \
-            const uint4 t = *reinterpret_cast<const uint4*>(p.A + (size_t)gm * p.lda + ch0 * 8 + \
-                                                            (KT) * GEMM_BK);                     \
-            ra[4 * j] = t.x; ra[4 * j + 1] = t.y; ra[4 * j + 2] = t.z; ra[4 * j + 3] = t.w;      \
-        }                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                         \
-            const int row = row0 + j * (NT / 8);                                                 \
-            const uint4 t = *reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + row) * p.ldw +   \
-                                                            ch0 * 8 + (KT) * GEMM_BK);           \
-            rb[4 * j] = t.x; rb[4 * j + 1] = t.y; rb[4 * j + 2] = t.z; rb[4 * j + 3] = t.w;      \
-        }                                                                                        \
-    }
-#define RS_STORE(BUF)                                                                            \
-    {                                                                                            \
-        char* sdst = smem + (BUF) * STAGE;                                                       \
-        _Pragma("unroll") for (int j = 0; j < CA; ++j) {                                         \
-            const int row = row0 + j * (NT / 8);                                                 \
-            *reinterpret_cast<uint4*>(sdst + row * ROW_BYTES + ((ch0 ^ ((row >> 1) & 7)) << 4)) = \
-                make_uint4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);              \
-        }                                                                                        \
-        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                         \
-            const int row = row0 + j * (NT / 8);                                                 \
-            *reinterpret_cast<uint4*>(sdst + (BM + row) * ROW_BYTES +                            \
-                                      ((ch0 ^ ((row >> 1) & 7)) << 4)) =                        \
-                make_uint4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);              \
-        }                                                                                        \
-    }
-    RS_LOAD(0)
-    RS_STORE(0)
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) RS_LOAD(kt + 1)
-        const char* sbase = smem + cur * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t af[TM], bfr[TN];
-            const int c = 2 * ks + half;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((c ^ aswz[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((c ^ bswz[j]) << 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (ROW_ON_LANE)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i],
-                                                                            acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j],
-                                                                            acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more) RS_STORE(cur ^ 1)
-        __syncthreads();
-    }
-}
-
-// NS > 0: LDS-DMA ring of NS stages; NS == -2: register-staged double buffer
-template <int BM, int BN, int WVM, int WVN, int NS, bool ROL>
-__device__ __forceinline__ void run_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
-                                             f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
-    if constexpr (NS > 0) gemm_mainloop<BM, BN, WVM, WVN, NS, ROL>(p, smem, m0, n0, acc);  // NS encodes ring depth and K-tile depth
-    else gemm_mainloop_rs<BM, BN, WVM, WVN, ROL>(p, smem, m0, n0, acc);
 }
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
@@ -347,11 +210,6 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     }
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
-#ifdef VT_STAGGER
-    // experiment: offset the second block of each CU by about half a K-tile so that the two
-    // co-resident blocks alternate load and MFMA phases instead of running in lockstep
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(VT_STAGGER);
-#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WVN, wc = wave % WVN, l31 = lane & 31, half = lane >> 5;
 
@@ -364,7 +222,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        run_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -410,7 +268,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
-            run_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
 #pragma unroll
@@ -457,7 +315,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t] with t contiguous (npad per row). MFMA with the
             // column (d) on the lane, 4 consecutive tokens per register quad.
-            run_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BM * 2 + 16;
             const int heads = p.D >> 6;
             if constexpr (FITS) __syncthreads();
@@ -512,33 +370,21 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     }
 }
 
-// Tile configurations {BM, BN, waves M x N, ring depth}:
+// Tile configurations {BM, BN, waves M x N, ring depth} of this file's kernel:
 //   0: 64x64   2x2 ring 4    small M, long K (fc2 of one or two streams)
 //   1: 128x128 2x2 ring 3
 //   2: 64x64   2x2 ring 2    small M: most blocks per CU
 //   3: 128x128 2x2 ring 2
-//   4: 256x256 2x4 ring 2    128 KiB LDS, 8 waves, one block per CU: half the global->LDS bytes per
-//                            FLOP of 128x128, which is what bounds these GEMMs (profiles/README.md)
-//   5: 256x128 4x2 ring 2    96 KiB LDS, for N = 768 where 256-wide column tiles leave a ragged grid
+// 17 is the 256x256 8-wave kernel of k_gemm256.hip. Numbers 4-16 were experiments on this kernel
+// (256-wide tiles with the same loop, 8-wave blocks, deeper rings, K-tile depth 32, register
+// staging) that never beat 128x128 ring 2 and were removed after the sweep kept in
+// profiles/gemm_sweep_r01.txt.
 #define GEMM_FOR_EACH_CFG(X, EPI) \
     X(0, 64, 64, 2, 2, 4, EPI)    \
     X(1, 128, 128, 2, 2, 3, EPI)  \
     X(2, 64, 64, 2, 2, 2, EPI)    \
-    X(3, 128, 128, 2, 2, 2, EPI)  \
-    X(4, 256, 256, 2, 4, 2, EPI)  \
-    X(5, 256, 128, 4, 2, 2, EPI)  \
-    X(6, 128, 128, 2, 4, 4, EPI)  \
-    X(7, 256, 128, 4, 2, 3, EPI)  \
-    X(8, 128, 128, 2, 4, 3, EPI)  \
-    X(9, 128, 128, 2, 2, -2, EPI) \
-    X(10, 64, 64, 2, 2, -2, EPI)  \
-    X(11, 256, 256, 2, 4, -2, EPI) \
-    X(12, 256, 128, 4, 2, -2, EPI) \
-    X(13, 256, 128, 4, 2, 35, EPI) \
-    X(14, 128, 128, 2, 2, 36, EPI) \
-    X(15, 256, 256, 2, 4, 36, EPI) \
-    X(16, 128, 256, 2, 4, 35, EPI)
-#define GEMM_NUM_CFG 18   // 0..16: this file's template; 17: k_gemm256.hip
+    X(3, 128, 128, 2, 2, 2, EPI)
+#define GEMM_NUM_CFG 18   // valid: 0..3 (this file) and 17 (k_gemm256.hip)
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
@@ -586,7 +432,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
 int gemm_pick_config(int M, int N, int K, int epilogue) {
     const char* env = getenv("VT_GEMM_CFG");   // tuning / test override
     const int forced = env ? atoi(env) : -1;
-    if (forced >= 0 && forced < GEMM_NUM_CFG) return forced;
+    if ((forced >= 0 && forced < 4) || forced == GEMM_CFG_256P8) return forced;
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
     // 256x256 8-wave kernel (k_gemm256.hip): one workgroup per CU, so it wants the grid to fill
@@ -609,11 +455,9 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
 }
 
 const char* gemm_config_name(int cfg) {
-    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "256x256x2",
-                              "256x128x2", "128x128w8x4", "256x128x3", "128x128w8x3", "128x128rs",
-                              "64x64rs", "256x256rs", "256x128rs", "256x128k32x3", "128x128k32x4",
-                              "256x256k32x4", "128x256k32x3", "256x256p8"};
-    return (cfg >= 0 && cfg < GEMM_NUM_CFG) ? n[cfg] : "?";
+    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
+    if (cfg == GEMM_CFG_256P8) return "256x256p8";
+    return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
 }
 
 template <int EPI>

@@ -34,10 +34,11 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
-    """each tile configuration (64x64 .. 256x256, ring 2..4) on a ragged M, against float32 NumPy"""
+    """each tile configuration (64x64 / 128x128 with ring 2..4, and the 256x256 8-wave kernel) on a
+    ragged M, against float32 NumPy"""
     monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
     rng = np.random.default_rng(cfg * 10 + epi)
     M, N, K = 720 + 37, 768, 384
@@ -56,7 +57,7 @@ def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17])
 def test_qkv_every_tile_config(gpu, monkeypatch, cfg):
     monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
     rng = np.random.default_rng(cfg)
