@@ -385,9 +385,11 @@ __global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __r
 //     test per step instead of per 32 keys.
 //   * The row sums come from a third P·V MFMA against a tile of ones (the matrix pipe was 28 % busy):
 //     they are the sums of the bf16-rounded probabilities, the values the numerator uses.
-//   * Lazy running maximum with a threshold (ATT_LAZY_LOG2): with 32 queries per wave a slightly
-//     larger score turns up in most steps, so a plain "max grew" test took the rescale branch
-//     almost every step.
+//   * No running-maximum bookkeeping in the common case: scores are used as they come out of the
+//     MFMA (p = 2^s) while they stay within +-32 log2 units; the reference moves (with a rescale)
+//     only when a query's maximum leaves that window. With 32 queries per wave a plain "max grew"
+//     test took the rescale branch in almost every step, and the per-step subtraction of the
+//     running maximum was 32 of the ~115 VALU instructions of a step.
 //   Measured and dropped (B = 30, 720 tokens, 12 heads; this kernel 74 us = 650 TFLOP/s, mode 2
 //   103 us): feeding -m_run as the C operand of the first QK MFMA to save the VALU subtraction
 //   (+16 VGPRs -> 2 instead of 3 waves per SIMD: 81 us); an 8-wave variant with the two wave groups
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __r
 //   SIMD hide about two thirds of it.
 //   * The output tile is transposed through LDS and stored as whole 128-B rows.
 #define AT3_STAGE 16384
+#define ATT_WIN 32.0f          // half-width of the score window inside which the reference stays put
 #define AT3_NS 3
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {
@@ -475,7 +478,13 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
     f32x16_t o0, o1, osum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; osum[r] = 0.0f; }
-    float m_run = 0.0f;                  // replaced by the true maximum in the first step
+    // Softmax reference: p = 2^(score - m_run). m_run stays 0 - no subtraction pass at all - while
+    // every query's scores stay inside [-ATT_WIN, +ATT_WIN] log2 units (p <= 2^32 is harmless in
+    // bf16 / f32 and the normalisation at the end divides it out); it moves, with a rescale of what
+    // has been accumulated, only when a maximum leaves that window (upwards in any step; downwards
+    // in the first step, so that a row of uniformly tiny scores does not underflow).
+    float m_run = 0.0f;
+    bool shifted = false;                // wave-uniform: some lane's m_run != 0
     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
     AT3_STAGE_TILE(0, 0)
@@ -521,8 +530,10 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
                 if (key + 32 >= tokens) s1[r] = -INFINITY;
             }
         }
+        if (shifted) {                      // wave-uniform, rare: scores relative to the moved reference
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }   // scores relative to the running max
+            for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }
+        }
         // ---- online softmax over the 64 keys of the step (per lane: one query, 32 scores) ----
         float mx = max3f(s0[0], s0[1], s0[2]);
 #pragma unroll
@@ -532,12 +543,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
         for (int r = 1; r < 15; r += 2) mx = max3f(mx, s1[r], s1[r + 1]);
         mx = fmaxf(mx, s1[15]);
         mx = xhalf_max(mx);                 // max of (score - m_run) over the query's 64 keys
-        const bool first = kt == 0;         // the first step adopts its maximum whatever its sign
-        if (first || !__all(mx <= ATT_LAZY_LOG2)) {  // else: some query's max grew (wave-uniform branch,
-                                            // rare after the first steps): move to the new max
+        const bool first = kt == 0;
+        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {   // wave-uniform, rare
             const float dm = first ? mx : fmaxf(mx, 0.0f);          // m_new - m_run, per lane
             const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);   // O and the sum are 0 in step 0
             m_run += dm;
+            shifted = true;
             osum[0] *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

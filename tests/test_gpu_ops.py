@@ -240,8 +240,8 @@ def test_attention_mode3(gpu, monkeypatch, B, N, H, scale):
 
 @pytest.mark.parametrize("mode", [0, 2, 3])
 def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
-    """scores that grow by far more than the lazy-max threshold (2^8) late in the key sequence:
-    the running maximum must move and everything accumulated before be rescaled"""
+    """scores that grow by far more than the lazy-max threshold / score window late in the key
+    sequence: the reference must move and everything accumulated before be rescaled"""
     monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     rng = np.random.default_rng(77)
     B, N, H = 1, 320, 2
@@ -257,6 +257,30 @@ def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
     err = np.abs(got - ref)
     assert np.isfinite(got).all()
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("level", [-20.0, -64.0, -150.0, 90.0])
+def test_attention_uniformly_offset_scores(gpu, monkeypatch, mode, level):
+    """every score of every query sits near `level` (log2 units): inside the window the kernel uses
+    p = 2^s as is (-20), below it the first step must adopt the maximum or the row would underflow
+    (-64, -150), above it the reference must move before 2^s overflows (+90)"""
+    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
+    rng = np.random.default_rng(int(abs(level)))
+    B, N, H = 1, 192, 1
+    q = np.zeros((N, 64), np.float32)
+    k = np.zeros((N, 64), np.float32)
+    q[:, 0] = 1.0
+    k[:, 0] = level                                   # common offset: q.k = level + small part
+    q[:, 1:] = bf16_round(rng.standard_normal((N, 63)).astype(np.float32) * 0.25)
+    k[:, 1:] = bf16_round(rng.standard_normal((N, 63)).astype(np.float32) * 0.5)
+    vb, v = _rand_bf16(gpu, rng, (N, 64))
+    qb, kb = _bits(gpu, q), _bits(gpu, k)
+    q, k = gpu.weights.bf16_bits_to_f32(qb), gpu.weights.bf16_bits_to_f32(kb)
+    ref = _attn_ref(q, k, v, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 0.02 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("cfg", [2, 3, 17])
