@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
 }
 
 // mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
-// 3 = LDS-DMA ring with permuted Vt (default when tokens % 16 == 0 and npad % 64 == 0), -1 = choose.
+// 3 = LDS-DMA ring with permuted Vt (default when tokens % 4 == 0 and npad % 64 == 0), -1 = choose.
 int attention_pick_mode(int tokens, int npad) {
     static const int forced = [] {
         const char* e = getenv("VT_ATTN_MODE");
@@ -615,7 +615,7 @@ int attention_pick_mode(int tokens, int npad) {
     }();
     if (forced >= 0 && forced <= 3) return forced;
     if (npad % 64 != 0) return 0;
-    return (tokens % 16 == 0) ? 3 : 2;
+    return (tokens % 4 == 0) ? 3 : 2;   // tokens % 4: the QKV epilogue's 4-token runs stay inside a stream
 }
 
 // once per device, outside any stream capture (nothing to raise at present: all LDS is static)
@@ -626,7 +626,7 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
     const int nqb = (tokens + 31) / 32;
     if (mode < 0) mode = attention_pick_mode(tokens, npad);
     if (mode >= 2 && npad % 64 != 0) return hipErrorInvalidValue;
-    if (mode == 3 && tokens % 16 != 0) return hipErrorInvalidValue;   // a 16-key group must not straddle streams
+    if (mode == 3 && tokens % 4 != 0) return hipErrorInvalidValue;
     if (mode == 0) {
         hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
                            tokens, H, npad);

@@ -329,8 +329,11 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
                     for (int q = 0; q < 4; ++q) {
                         const int mr = wr * WM + i * 32 + 8 * q + 4 * half;
                         // permuted Vt layout (attention mode 3): the 4-token run moves inside its
-                        // group of 16 (groups never straddle streams: tokens % 16 == 0 then)
-                        const int mp = p.vt_perm ? attn_perm16(mr) : mr;
+                        // group of 16. Streams on 16-token boundaries: permute the tile-local index
+                        // here; otherwise (e.g. 980 tokens) each run is placed by its own stream's
+                        // token index when it is written out
+                        const bool perm_general = p.vt_perm && (p.tokens & 15);
+                        const int mp = (p.vt_perm && !perm_general) ? attn_perm16(mr) : mr;
                         const uint2 pk = make_uint2(
                             pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
                             pack_bf16x2(acc[i][j][4 * q + 2] + bias, acc[i][j][4 * q + 3] + bias));
@@ -339,13 +342,26 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
                         } else if (m0 + mr < p.M) {
                             const int m = m0 + mp, nv = n0 + nr - 2 * p.D;
                             const int b = m / p.tokens, t = m % p.tokens;
-                            bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
+                            bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad +
+                                          (perm_general ? attn_perm16(t) : t);
                             *reinterpret_cast<uint2*>(dst) = pk;
                         }
                     }
                 }
             if constexpr (FITS) {
                 __syncthreads();
+                if (p.vt_perm && (p.tokens & 15)) {      // run by run, 8-B stores (see above)
+                    constexpr int CR = BM / 4;           // 4-token runs per d-row
+                    for (int c = threadIdx.x; c < BN * CR; c += NT) {
+                        const int r = c / CR, cr = c % CR;
+                        const int m = m0 + cr * 4, nv = n0 + r - 2 * p.D;
+                        if (m >= p.M) continue;
+                        const int b = m / p.tokens, t = m % p.tokens;
+                        bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + attn_perm16(t);
+                        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(smem + r * STRIDE + cr * 8);
+                    }
+                    return;
+                }
                 constexpr int CH = BM / 8;   // 16-B pieces (8 tokens) per d-row
                 for (int c = threadIdx.x; c < BN * CH; c += NT) {
                     const int r = c / CH, ch = c % CH;

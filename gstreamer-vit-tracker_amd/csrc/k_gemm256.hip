@@ -379,7 +379,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         for (int mf = 0; mf < 4; ++mf) {
                             // 4-token run q of the 16-token group: runs 1 and 2 swap places in
                             // the permuted layout (attn_perm16)
-                            const int qp = p.vt_perm ? ((q & 1) << 1 | (q >> 1)) : q;
+                            // (only when streams start on 16-token boundaries; otherwise the
+                            // runs are placed one by one in the read-out below)
+                            const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
                             const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
                             const f32x4_t a = acc[i][mf][j][nf];
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
@@ -388,6 +390,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         }
                 }
             __syncthreads();
+            if (p.vt_perm && (p.tokens & 15)) {
+                // permuted layout with streams that do not start on 16-token boundaries (e.g. 980
+                // tokens): every 4-token run goes to attn_perm16 of ITS stream's token index - 8-B
+                // stores, twice as many as the aligned case
+                const int c8r = tid & 63;
+                for (int it = 0; it < 32; ++it) {
+                    const int r = it * 8 + (tid >> 6);
+                    const int m = m0 + c8r * 4, nv = n0 + r - 2 * p.D;
+                    if (m >= p.M) continue;
+                    const int b = m / p.tokens, t = m % p.tokens;        // tokens % 4 == 0: runs never straddle
+                    bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + attn_perm16(t);
+                    *reinterpret_cast<uint2*>(dst) =
+                        *reinterpret_cast<const uint2*>(smem + r * 512 + ((c8r ^ ((r & 7) << 1)) << 3));
+                }
+                return;
+            }
             const int c16 = tid & 31;
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 16 + (tid >> 5);

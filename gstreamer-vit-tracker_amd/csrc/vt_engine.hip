@@ -1342,7 +1342,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = D; g.W = (const bf16_t*)dw.p; g.ldw = D; g.bias = (const float*)db.p;
     g.M = M; g.N = 3 * D; g.K = D; g.qk = (bf16_t*)dqk.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
-    g.vt_perm = (getenv("VT_QKV_PERM") && atoi(getenv("VT_QKV_PERM")) && tokens % 16 == 0) ? 1 : 0;   // tests: the mode-3 attention layout
+    g.vt_perm = (getenv("VT_QKV_PERM") && atoi(getenv("VT_QKV_PERM"))) ? 1 : 0;   // tests: the mode-3 attention layout
     HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
     HIPCHK(hipDeviceSynchronize());
     auto widen = [](const DevBuf& d, size_t count, float* out) -> hipError_t {

@@ -219,11 +219,13 @@ def test_attention(gpu, monkeypatch, B, N, H, scale, mode):
 
 
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
-                                         (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0)])
+                                         (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
+                                         (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
 def test_attention_mode3(gpu, monkeypatch, B, N, H, scale):
-    """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 16 == 0).
-    Covers a single partial tile (16), a tail of 16 and of 32 keys (80, 720 / 96), full tiles (320),
-    more tiles than ring stages (1008) and a ragged last query block."""
+    """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
+    Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
+    (320), more tiles than ring stages (1008), token counts that are not multiples of 16 (100, 980,
+    36: the last 16-key group is partly padding) and a ragged last query block."""
     monkeypatch.setenv("VT_ATTN_MODE", "3")
     rng = np.random.default_rng(N + H)
     D = H * 64
@@ -284,13 +286,15 @@ def test_attention_uniformly_offset_scores(gpu, monkeypatch, mode, level):
 
 
 @pytest.mark.parametrize("cfg", [2, 3, 17])
-def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg):
-    """Vt as attention mode 3 reads it: inside every group of 16 tokens the 4-token runs 1 and 2
-    swap places (position = token with bits 2 and 3 exchanged)"""
+@pytest.mark.parametrize("tokens", [112, 100])
+def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg, tokens):
+    """Vt as attention mode 3 reads it: inside every group of 16 tokens OF A STREAM the 4-token runs
+    1 and 2 swap places (position = token with bits 2 and 3 exchanged). 112: streams start on
+    16-token boundaries (whole 16-B pieces); 100: they do not (run-by-run placement)"""
     monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
     monkeypatch.setenv("VT_QKV_PERM", "1")
     rng = np.random.default_rng(cfg)
-    B, tokens, D = 3, 112, 768
+    B, D = 3, 768
     ab, a = _rand_bf16(gpu, rng, (B * tokens, D))
     wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
     bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
@@ -301,6 +305,8 @@ def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg):
     pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
     got = vt_[:, :, pos]           # got[..., t] = stored position of token t
     assert np.all(np.abs(got - v) <= np.abs(v) * 2 ** -8 + 1e-3)
+    unused = np.setdiff1d(np.arange(vt_.shape[2]), pos)
+    assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
