@@ -83,7 +83,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_recommended_streams", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
@@ -139,6 +139,7 @@ def lib():
     L.vt_group_enqueue_device.argtypes = [c_void_p, POINTER(CFrame), c_int]
     L.vt_group_wait.argtypes = [c_void_p, POINTER(CResult), c_int]
     L.vt_group_update_device.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
+    L.vt_recommended_streams.argtypes = [POINTER(CModelInfo), c_int]
     L.vt_group_init_host.argtypes = [c_void_p, c_int, POINTER(CFrame), CBBox]
     L.vt_group_update_host.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
     L.vt_group_hip_stream.argtypes = [c_void_p]
@@ -174,6 +175,11 @@ def _check(rc):
     if rc < 0:
         raise VtError(rc, lib().vt_last_error().decode(errors="replace"))
     return rc
+
+
+def recommended_streams(info: "CModelInfo", max_streams: int = 128) -> int:
+    """vt_recommended_streams: streams per group that fill the 256 CUs in whole GEMM rounds"""
+    return lib().vt_recommended_streams(byref(info), max_streams)
 
 
 def device_count() -> int:

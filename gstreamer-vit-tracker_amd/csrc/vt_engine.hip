@@ -667,6 +667,22 @@ int vt_device_count(void) {
     return ok;
 }
 
+int vt_recommended_streams(const vt_model_info* info, int max_streams) {
+    if (!info || info->dim <= 0 || (info->dim % 256) != 0 || max_streams < 1) return 1;
+    const long tokens = (long)info->tokens_template + info->tokens_search;
+    const long cols[3] = {info->dim / 256, 3L * info->dim / 256, info->mlp_dim / 256};
+    for (int b = 1; b <= max_streams; ++b) {
+        const long rows = (b * tokens + 255) / 256;
+        bool ok = true;
+        for (long c : cols) {
+            const long t = rows * c, rounds = (t + 255) / 256;
+            if (c <= 0 || t * 100 < rounds * 256 * 98) ok = false;   // < 98 % of the rounds' CU slots used
+        }
+        if (ok) return b;
+    }
+    return 1;
+}
+
 int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out) {
     if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;

@@ -93,6 +93,11 @@ void vt_config_default(vt_config* cfg);
 const char* vt_last_error(void);       /* thread-local text of the last failure */
 int vt_abi_version(void);
 int vt_device_count(void);             /* gfx950 devices visible; 0 → vt_create fails */
+/* Streams per vt_group that fill the MI355X's 256 CUs in whole rounds of the 256x256 GEMM kernel
+ * (the smallest batch <= max_streams whose worst encoder GEMM wastes < 2 % of its rounds; 1 if
+ * there is none or the model's width does not fit that kernel). No reference counterpart: the
+ * reference runs one tracker per process (src/pipeline.rs:55). Needs no GPU. */
+int vt_recommended_streams(const vt_model_info* info, int max_streams);
 
 /* ---- single stream: the literal drop-in ------------------------------------------------ */
 

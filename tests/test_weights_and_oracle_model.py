@@ -116,3 +116,12 @@ def test_recommended_streams_fill_whole_gemm_rounds(vt):
     for name in ("cfg2", "cfg5"):
         b = vt.weights.recommended_streams(name)
         assert 1 < b <= 128
+
+
+def test_c_abi_recommended_streams_matches_python(vt):
+    for name in ("cfg2", "cfg3", "cfg5", "tiny"):
+        cfg = vt.weights.get_config(name)
+        mi = vt.CModelInfo()
+        mi.dim, mi.mlp_dim = cfg.dim, cfg.mlp_dim
+        mi.tokens_template, mi.tokens_search = cfg.n_t, cfg.n_s
+        assert vt.recommended_streams(mi) == vt.weights.recommended_streams(name)
