@@ -83,7 +83,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_recommended_streams", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_recommended_streams", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
@@ -140,6 +140,10 @@ def lib():
     L.vt_group_wait.argtypes = [c_void_p, POINTER(CResult), c_int]
     L.vt_group_update_device.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
     L.vt_recommended_streams.argtypes = [POINTER(CModelInfo), c_int]
+    L.vt_import_dmabuf.argtypes = [c_int, c_int, c_size_t, POINTER(c_void_p), POINTER(c_void_p)]
+    L.vt_release_dmabuf.argtypes = [c_void_p]
+    L.vt_release_dmabuf.restype = None
+    L.vt_export_dmabuf.argtypes = [c_int, c_void_p, c_size_t, POINTER(c_int)]
     L.vt_group_init_host.argtypes = [c_void_p, c_int, POINTER(CFrame), CBBox]
     L.vt_group_update_host.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
     L.vt_group_hip_stream.argtypes = [c_void_p]
@@ -180,6 +184,28 @@ def _check(rc):
 def recommended_streams(info: "CModelInfo", max_streams: int = 128) -> int:
     """vt_recommended_streams: streams per group that fill the 256 CUs in whole GEMM rounds"""
     return lib().vt_recommended_streams(byref(info), max_streams)
+
+
+class DmaBuf:
+    """a dma-buf mapped into device memory (vt_import_dmabuf); .ptr is usable as a frame plane"""
+
+    def __init__(self, fd: int, nbytes: int, device: int = 0):
+        self._h, p = c_void_p(), c_void_p()
+        _check(lib().vt_import_dmabuf(device, fd, nbytes, byref(self._h), byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().vt_release_dmabuf(self._h)
+            self._h = c_void_p()
+
+    __del__ = close
+
+
+def export_dmabuf(d_ptr: int, nbytes: int, device: int = 0) -> int:
+    fd = c_int(-1)
+    _check(lib().vt_export_dmabuf(device, d_ptr, nbytes, byref(fd)))
+    return fd.value
 
 
 def device_count() -> int:

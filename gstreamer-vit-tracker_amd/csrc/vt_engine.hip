@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vt_common.hpp"
+#include <unistd.h>
 
 // ---- error plumbing ------------------------------------------------------------------------------
 
@@ -665,6 +666,65 @@ int vt_device_count(void) {
         if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
     }
     return ok;
+}
+
+struct vt_extmem {
+    int device;
+    hipExternalMemory_t mem;
+};
+
+int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr) {
+    if (!out || !d_ptr || fd < 0 || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    *out = nullptr; *d_ptr = nullptr;
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    const int dupfd = dup(fd);     // the import takes the descriptor over; the caller keeps its own
+    if (dupfd < 0) return set_err(VT_ERR_INVALID_ARG, "dup(fd) failed");
+    hipExternalMemoryHandleDesc hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+    hd.handle.fd = dupfd;
+    hd.size = bytes;
+    hipExternalMemory_t mem = nullptr;
+    hipError_t he = hipImportExternalMemory(&mem, &hd);
+    if (he != hipSuccess) {
+        close(dupfd);
+        return set_err(VT_ERR_HIP, "hipImportExternalMemory(dma-buf): %s", hipGetErrorString(he));
+    }
+    hipExternalMemoryBufferDesc bd;
+    memset(&bd, 0, sizeof(bd));
+    bd.offset = 0; bd.size = bytes;
+    void* p = nullptr;
+    he = hipExternalMemoryGetMappedBuffer(&p, mem, &bd);
+    if (he != hipSuccess || !p) {
+        (void)hipDestroyExternalMemory(mem);
+        return set_err(VT_ERR_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(he));
+    }
+    *out = new vt_extmem{device_id, mem};
+    *d_ptr = p;
+    return VT_OK;
+}
+
+void vt_release_dmabuf(vt_extmem* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
+    (void)hipDestroyExternalMemory(m->mem);
+    delete m;
+}
+
+int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out) {
+    if (!d_ptr || !fd_out || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    *fd_out = -1;
+    if (int rc = check_device(device_id)) return rc;
+    HIPCHK(hipSetDevice(device_id));
+    int fd = -1;
+    hipError_t he = hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)d_ptr, bytes,
+                                                   hipMemRangeHandleTypeDmaBufFd, 0);
+    if (he != hipSuccess || fd < 0)
+        return set_err(VT_ERR_HIP, "hipMemGetHandleForAddressRange(dma-buf): %s", hipGetErrorString(he));
+    *fd_out = fd;
+    return VT_OK;
 }
 
 int vt_recommended_streams(const vt_model_info* info, int max_streams) {

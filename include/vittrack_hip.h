@@ -187,6 +187,21 @@ void* vt_group_hip_stream(vt_group* g);
 int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box);
 int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out);
 
+/* ---- dma-buf ingest ------------------------------------------------------------------------
+ * The reference's capture side can hand out dma-bufs (v4l2src io-mode=dmabuf, src/pipeline_ir.rs:24)
+ * but then maps them on the CPU (src/pipeline.rs:95-101). vt_import_dmabuf maps a dma-buf fd into
+ * this device's address space (hipImportExternalMemory); *d_ptr may then be used as plane0 / plane1
+ * of a vt_frame with the *_device entry points: no staging copy in host memory. The fd stays owned
+ * by the caller (the library imports a dup). Whether a given exporter's buffers are importable is
+ * up to the amdgpu driver; an import that the driver refuses returns VT_ERR_HIP and the caller
+ * falls back to the host-pointer entry points. */
+typedef struct vt_extmem vt_extmem;
+int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr);
+void vt_release_dmabuf(vt_extmem* m);
+/* Export a range of a hipMalloc'ed allocation as a dma-buf fd (page-aligned pointer and size; the
+ * caller closes the fd). Tooling: used by the tests to exercise the import path on this machine. */
+int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out);
+
 /* ---- reference colour converter on the GPU ---------------------------------------------- */
 
 /* ≙ nv12_full_to_rgb_parallel(nv12_data, width, height) (src/nv12_convert.rs:46-92): packed NV12

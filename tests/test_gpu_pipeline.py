@@ -307,6 +307,47 @@ def test_group_host_frames_equal_device_frames(gpu, weights_tiny):
         g_host.update_host(hf[:2])          # a pass needs one frame per stream
 
 
+def test_dmabuf_import_roundtrip_tracks_like_the_source_buffer(gpu, weights_tiny):
+    """vt_import_dmabuf: a frame that lives in a dma-buf is tracked through the mapping, without a
+    host copy. The only dma-buf exporter on this machine is the GPU itself, so the test exports a
+    device allocation (vt_export_dmabuf), imports the fd back and checks that tracking through the
+    mapping gives exactly the results of tracking on the original pointer while a new frame is
+    written into the buffer every step (so the mapping must alias the same memory). Skips if the driver refuses either step."""
+    import os
+    import torch
+    w, h = 640, 480
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=21)
+    nbytes = 1 << 21                                    # one 2 MiB allocation: page-aligned range
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    if buf.data_ptr() % 4096:
+        pytest.skip("allocator returned an unaligned block")
+    try:
+        fd = gpu.export_dmabuf(buf.data_ptr(), nbytes)
+    except gpu.VtError as e:
+        pytest.skip(f"dma-buf export not available here: {e}")
+    try:
+        try:
+            mapped = gpu.DmaBuf(fd, nbytes)
+        except gpu.VtError as e:
+            pytest.skip(f"dma-buf import refused by the driver: {e}")
+        fb = w * h * 3 // 2
+        t_src, t_map = gpu.VitTrack(weights_tiny), gpu.VitTrack(weights_tiny)
+        for t in range(6):
+            frame = torch.from_numpy(sc.frame_nv12(t)).cuda()
+            buf[:fb] = frame                             # the "capture" writes into the dma-buf
+            torch.cuda.synchronize()
+            if t == 0:
+                box = gpu.BBox.new(*sc.gt_box(0))
+                t_src.init_nv12_device(buf.data_ptr(), buf.data_ptr() + w * h, w, h, w, w, box)
+                t_map.init_nv12_device(mapped.ptr, mapped.ptr + w * h, w, h, w, w, box)
+            a = t_src.update_nv12_device(buf.data_ptr(), buf.data_ptr() + w * h, w, h, w, w)
+            b = t_map.update_nv12_device(mapped.ptr, mapped.ptr + w * h, w, h, w, w)
+            assert a.success and a.bbox == b.bbox and abs(a.score - b.score) < 1e-6
+        mapped.close()
+    finally:
+        os.close(fd)
+
+
 def test_errors_do_not_abort(gpu, weights_tiny, tmp_path):
     with pytest.raises(gpu.VtError):
         gpu.VitTrack.new(str(tmp_path / "missing.vtw"))
