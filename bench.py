@@ -186,7 +186,7 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": wl_text, "model": cfg_name, "frame": f"{fw}x{fh} NV12",
+        "config": {"workload": wl_text, "vit_config": cfg_name, "frame": f"{fw}x{fh} NV12",
                    "streams_per_gpu": B, "engines_per_gpu": G, "tokens": mi.tokens_template + mi.tokens_search,
                    "ingest": "frames resident in HBM", "launch": "eager" if args.eager else "hipGraph",
                    "weights": "synthetic seeded encoder + fitted head (no reference weights exist)"},
