@@ -2,8 +2,9 @@
 
   gstreamer-vit-tracker_amd/libvittrack_hip.so   HIP kernels + C ABI (include/vittrack_hip.h),
                                                  code object for gfx950 only
-  gstreamer-vit-tracker_amd/libvittrack_host.so  C++ mirror of the reference host logic
-                                                 (include/vittrack_host.h)
+  harness/libvittrack_host.so                    replay harness: C++ mirror of the reference host
+                                                 logic (include/vittrack_host.h); NOT product code,
+                                                 libvittrack_hip.so does not link it
 
 hipcc cross-compiles gfx950 without a GPU. The .so files are git-ignored but travel to the GPU
 box with the snapshot.
@@ -17,10 +18,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-HOST = os.path.join(PKG, "host")
+HOST = os.path.join(PKG, "..", "harness")
 OBJ = os.path.join(PKG, "build")
 LIB_HIP = os.path.join(PKG, "libvittrack_hip.so")
-LIB_HOST = os.path.join(PKG, "libvittrack_host.so")
+LIB_HOST = os.path.join(HOST, "libvittrack_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_gemm256.hip", "k_attn.hip", "k_misc.hip", "k_overlay.hip",

@@ -2,7 +2,7 @@
 #include <cstring>
 #include <string>
 
-#include "../../include/vittrack_host.h"
+#include "../include/vittrack_host.h"
 #include "tracker_context.hpp"
 
 using host::TrackerContext;

@@ -9,7 +9,7 @@ from ctypes import (CFUNCTYPE, POINTER, Structure, byref, c_char_p, c_double, c_
 
 import numpy as np
 
-from . import CBBox, CResult, VtError
+from gstreamer_vit_tracker_amd import CBBox, CResult, VtError
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libvittrack_host.so")

@@ -1,4 +1,5 @@
-// tracker_context.hpp — C++ mirror of the reference's tracker control layer:
+// tracker_context.hpp — REPLAY HARNESS (not product logic; libvittrack_hip.so does not link it).
+// C++ mirror of the reference's tracker control layer:
 //   AppState        /root/reference/src/app_state.rs:1-6
 //   UserCommand     /root/reference/src/user_commands.rs:1-10
 //   SelectionState  /root/reference/src/selection_state.rs:1-46

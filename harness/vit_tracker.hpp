@@ -11,7 +11,7 @@
 #include <memory>
 #include <string>
 
-#include "../../include/vittrack_hip.h"
+#include "../include/vittrack_hip.h"
 
 namespace vit_tracker {
 
@@ -82,7 +82,7 @@ struct HipApi {
                 dir = p == std::string::npos ? "." : dir.substr(0, p);
             }
             const char* env = getenv("VITTRACK_HIP_LIB");
-            std::string path = env ? env : dir + "/libvittrack_hip.so";
+            std::string path = env ? env : dir + "/../gstreamer-vit-tracker_amd/libvittrack_hip.so";
             api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (!api.handle) {
                 load_err = std::string("cannot load ") + path + ": " + dlerror();

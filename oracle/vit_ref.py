@@ -243,15 +243,48 @@ def im2col3x3(t, grid):
     return np.concatenate(cols, axis=1)
 
 
+def parse_vtwb(raw: bytes):
+    """The oracle's OWN reader of the "VTWB0001" weight blob (layout: DESIGN.md §2; the product's
+    writer is gstreamer-vit-tracker_amd/weights.py and its reader csrc/vt_engine.hip `index_blob` —
+    neither is imported here, so a layout mistake on either side shows up as a parity failure).
+      [0,8) magic; [8,88) 20 x int32: version, patch, template, search, dim, heads, layers, mlp_dim,
+      head_ch, kpad, n_tensors, seed; [88,120) 8 x float32: norm_a[3], norm_b[3], success
+      threshold, LayerNorm eps; table at 256, 64 B per entry: name[32], dtype u32 (0 f32, 1 bf16),
+      rows u32, cols u32, pad u32, offset u64, nbytes u64.
+    -> (header dict, {name: float32 or uint16 2-D array})"""
+    import struct
+    if len(raw) < 256 or raw[:8] != b"VTWB0001":
+        raise ValueError("not a VTWB0001 blob")
+    iv = struct.unpack_from("<20i", raw, 8)
+    fv = struct.unpack_from("<8f", raw, 88)
+    keys = ("version", "patch", "template", "search", "dim", "heads", "layers", "mlp_dim",
+            "head_ch", "kpad", "n_tensors", "seed")
+    hdr = dict(zip(keys, iv))
+    if hdr["version"] != 1:
+        raise ValueError(f"VTWB version {hdr['version']}")
+    hdr["norm_a"] = np.array(fv[0:3], np.float32)
+    hdr["norm_b"] = np.array(fv[3:6], np.float32)
+    hdr["success_threshold"], hdr["ln_eps"] = fv[6], fv[7]
+    tens = {}
+    for i in range(hdr["n_tensors"]):
+        name, code, rows, cols, _pad, off, nbytes = struct.unpack_from("<32sIIIIQQ", raw,
+                                                                        256 + 64 * i)
+        dt = np.dtype("<u2") if code == 1 else np.dtype("<f4")
+        if code > 1 or nbytes != rows * cols * dt.itemsize or off + nbytes > len(raw):
+            raise ValueError(f"VTWB tensor {name!r} malformed")
+        tens[name.split(b"\0")[0].decode()] = np.frombuffer(raw, dt, rows * cols, off).reshape(
+            rows, cols)
+    return hdr, tens
+
+
 class Model:
     def __init__(self, blob_path_or_bytes):
-        import gstreamer_vit_tracker_amd.weights as W
         if isinstance(blob_path_or_bytes, (bytes, bytearray, memoryview)):
             raw = bytes(blob_path_or_bytes)
         else:
             with open(blob_path_or_bytes, "rb") as f:
                 raw = f.read()
-        self.hdr, tens = W.parse_blob(raw)
+        self.hdr, tens = parse_vtwb(raw)
         self.t = {k: (bf16_bits_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32))
                   for k, v in tens.items()}
         h = self.hdr

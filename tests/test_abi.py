@@ -25,7 +25,7 @@ def test_hip_library_exports_every_declared_symbol(vt):
 
 
 def test_host_library_exports_every_declared_symbol(vt):
-    from gstreamer_vit_tracker_amd import hostlib
+    from harness import hostlib
     names = _declared("vittrack_host.h")
     L = hostlib.lib()
     missing = [n for n in names if not hasattr(L, n)]

@@ -26,7 +26,7 @@ class OracleTracker:
 
 @pytest.mark.parametrize("nv12", [True, False])
 def test_probe_sequence_select_track(gpu, oracle, weights_tiny, nv12):
-    from gstreamer_vit_tracker_amd import hostlib
+    from harness import hostlib
     w, h = 640, 480
     sc = gpu.synth.MovingSquare(w, h, 64, seed=5)
     ctx = hostlib.TrackerContext.new(weights_tiny, w, h)
@@ -73,7 +73,7 @@ def test_probe_sequence_select_track(gpu, oracle, weights_tiny, nv12):
 
 
 def test_host_nv12_full_to_rgb_through_host_lib(gpu, oracle):
-    from gstreamer_vit_tracker_amd import hostlib
+    from harness import hostlib
     import ctypes
     w, h = 320, 240
     sc = gpu.synth.MovingSquare(w, h, 48, seed=9)

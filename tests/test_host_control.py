@@ -11,7 +11,7 @@ from oracle import tracker_context_ref as ref
 
 @pytest.fixture(scope="module")
 def hostlib(vt):
-    from gstreamer_vit_tracker_amd import hostlib as h
+    from harness import hostlib as h
     h.lib()
     return h
 
