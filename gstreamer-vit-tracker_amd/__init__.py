@@ -41,7 +41,8 @@ class CResult(Structure):
 class CConfig(Structure):
     _fields_ = [("struct_size", c_uint32), ("success_threshold", c_float), ("use_graph", c_int32),
                 ("n_streams", c_int32), ("max_frame_width", c_int32),
-                ("max_frame_height", c_int32), ("reserved", c_int32 * 8)]
+                ("max_frame_height", c_int32), ("max_device_mib", c_int32),
+                ("reserved", c_int32 * 7)]
 
 
 class CModelInfo(Structure):
@@ -57,7 +58,7 @@ class CFrame(Structure):
     _fields_ = [("plane0", c_void_p), ("plane1", c_void_p), ("width", c_int32),
                 ("height", c_int32), ("stride0", c_int32), ("stride1", c_int32),
                 ("format", c_int32), ("origin_x", c_int32), ("origin_y", c_int32),
-                ("reserved", c_int32)]
+                ("windowed", c_int32), ("window_w", c_int32), ("window_h", c_int32)]
 
 
 class CDrawCmd(Structure):
@@ -165,10 +166,10 @@ def lib():
     L.vt_overlay_rgb8_device.argtypes = L.vt_overlay_nv12_device.argtypes
     L.vt_overlay_rgb8.argtypes = L.vt_overlay_nv12.argtypes
     u16p, fp = POINTER(c_uint16), POINTER(c_float)
-    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int]
+    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int]
     L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
-    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int]
-    L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int]
+    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int, c_int, c_int]
+    L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
     L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
     _lib = L
@@ -224,13 +225,15 @@ def _f32(a):
     return a.ctypes.data_as(POINTER(c_float))
 
 
-def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, max_h=0) -> CConfig:
+def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, max_h=0,
+                max_device_mib=0) -> CConfig:
     c = CConfig()
     lib().vt_config_default(byref(c))
     c.success_threshold = success_threshold
     c.use_graph = 1 if use_graph else 0
     c.n_streams = n_streams
     c.max_frame_width, c.max_frame_height = max_w, max_h
+    c.max_device_mib = max_device_mib
     return c
 
 
@@ -376,11 +379,11 @@ class VitTrack:
 
 
 def frame_nv12(d_y, d_uv, w, h, y_stride=None, uv_stride=None) -> CFrame:
-    return CFrame(d_y, d_uv, w, h, y_stride or w, uv_stride or ((w + 1) & ~1), PIX_NV12, 0, 0, 0)
+    return CFrame(d_y, d_uv, w, h, y_stride or w, uv_stride or ((w + 1) & ~1), PIX_NV12, 0, 0, 0, 0, 0)
 
 
 def frame_rgb8(d_rgb, w, h, stride=None) -> CFrame:
-    return CFrame(d_rgb, None, w, h, stride or 3 * w, 0, PIX_RGB8, 0, 0, 0)
+    return CFrame(d_rgb, None, w, h, stride or 3 * w, 0, PIX_RGB8, 0, 0, 0, 0, 0)
 
 
 class Group:
@@ -388,10 +391,10 @@ class Group:
 
     def __init__(self, weights_path: str | None = None, n_streams: int = 1, device: int = 0,
                  success_threshold: float = -1.0, use_graph: bool = True,
-                 device_blob: tuple[int, int] | None = None):
+                 device_blob: tuple[int, int] | None = None, max_device_mib: int = 0):
         self._h = c_void_p()
         self._owner = None
-        cfg = make_config(success_threshold, use_graph, n_streams)
+        cfg = make_config(success_threshold, use_graph, n_streams, max_device_mib=max_device_mib)
         if device_blob is not None:
             ptr, nbytes = device_blob
             _check(lib().vt_group_create_from_device_blob(ptr, nbytes, device, byref(cfg),
@@ -459,13 +462,13 @@ class Group:
         if isinstance(frame, NV12Frame):
             uv = frame.buf[frame.w * frame.h:]
             return CFrame(frame.buf.ctypes.data, uv.ctypes.data, frame.w, frame.h, frame.w,
-                          (frame.w + 1) & ~1, PIX_NV12, 0, 0, 0), frame
+                          (frame.w + 1) & ~1, PIX_NV12, 0, 0, 0, 0, 0), frame
         if isinstance(frame, YUY2Frame):
             return CFrame(frame.buf.ctypes.data, None, frame.w, frame.h, 2 * frame.w, 0, PIX_YUY2,
-                          0, 0, 0), frame
+                          0, 0, 0, 0, 0), frame
         a = np.ascontiguousarray(frame, np.uint8)
         h, w, _ = a.shape
-        return CFrame(a.ctypes.data, None, w, h, 3 * w, 0, PIX_RGB8, 0, 0, 0), a
+        return CFrame(a.ctypes.data, None, w, h, 3 * w, 0, PIX_RGB8, 0, 0, 0, 0, 0), a
 
     def init_host(self, stream: int, frame, bbox: BBox):
         f, keep = self._host_frame(frame)
@@ -545,7 +548,7 @@ def overlay_rgb8(rgb: np.ndarray, cmds, device: int = 0) -> np.ndarray:
 
 # ---- operator-level entry points (numerics tests) -------------------------------------------
 
-def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0):
+def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1):
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
     w_bits = np.ascontiguousarray(w_bits, np.uint16)
     M, K = a_bits.shape
@@ -554,7 +557,7 @@ def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0):
                                                                                  np.float32).copy()
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     _check(lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
-                                 _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue))
+                                 _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue, cfg))
     return c
 
 
@@ -564,7 +567,7 @@ def op_gemm_bench(M, N, K, epilogue, cfg=-1, iters=50, device=0) -> float:
     return float(us.value)
 
 
-def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0):
+def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0, cfg=-1, vt_perm=0):
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
     w_bits = np.ascontiguousarray(w_bits, np.uint16)
     bias = np.ascontiguousarray(bias, np.float32)
@@ -572,15 +575,15 @@ def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0):
     qk = np.empty((B * tokens, 2 * D), np.float32)
     vt = np.empty((B * (D // 64), 64, npad), np.float32)
     _check(lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),
-                                _f32(vt), B, tokens, D))
+                                _f32(vt), B, tokens, D, cfg, vt_perm))
     return qk, vt
 
 
-def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0):
+def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0, mode=-1):
     q_bits, k_bits, v_bits = (np.ascontiguousarray(x, np.uint16) for x in (q_bits, k_bits, v_bits))
     out = np.empty((B * N, H * 64), np.float32)
     _check(lib().vt_op_attention_bf16(device, _u16(q_bits), _u16(k_bits), _u16(v_bits), _f32(out),
-                                      B, N, H))
+                                      B, N, H, mode))
     return out
 
 

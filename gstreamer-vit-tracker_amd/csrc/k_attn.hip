@@ -609,11 +609,6 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
 // mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
 // 3 = LDS-DMA ring with permuted Vt (default when tokens % 4 == 0 and npad % 64 == 0), -1 = choose.
 int attention_pick_mode(int tokens, int npad) {
-    static const int forced = [] {
-        const char* e = getenv("VT_ATTN_MODE");
-        return e ? atoi(e) : -1;
-    }();
-    if (forced >= 0 && forced <= 3) return forced;
     if (npad % 64 != 0) return 0;
     return (tokens % 4 == 0) ? 3 : 2;   // tokens % 4: the QKV epilogue's 4-token runs stay inside a stream
 }

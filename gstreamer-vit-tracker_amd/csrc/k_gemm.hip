@@ -21,8 +21,6 @@
 //     that the store side is wide: f32 outputs keep the column on the lane (128 B contiguous per
 //     row per store), bf16 row-major outputs put the ROW on the lane so each lane owns 4
 //     consecutive columns per accumulator quad (one 8-B store).
-#include <cstdlib>
-
 #include "vt_common.hpp"
 #include "k_gemm_util.hpp"
 
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(1, 128, 128, 2, 2, 3, EPI)  \
     X(2, 64, 64, 2, 2, 2, EPI)    \
     X(3, 128, 128, 2, 2, 2, EPI)
-#define GEMM_NUM_CFG 18   // valid: 0..3 (this file) and 17 (k_gemm256.hip)
+#define GEMM_NUM_CFG 19   // valid: 0..3 (this file) and 17, 18 (k_gemm256.hip)
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
@@ -446,9 +444,6 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
 // Chosen from sweeps on MI355X over the tracker's shapes (M = 720 * streams; profiles/
 // gemm_sweep_r01.txt).
 int gemm_pick_config(int M, int N, int K, int epilogue) {
-    const char* env = getenv("VT_GEMM_CFG");   // tuning / test override
-    const int forced = env ? atoi(env) : -1;
-    if ((forced >= 0 && forced < 4) || forced == GEMM_CFG_256P8) return forced;
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
     // 256x256 8-wave kernel (k_gemm256.hip): one workgroup per CU, so it wants the grid to fill
@@ -473,6 +468,7 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
 const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
     if (cfg == GEMM_CFG_256P8) return "256x256p8";
+    if (cfg == GEMM_CFG_256P4) return "256x256p4";
     return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
 }
 
@@ -491,7 +487,8 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
         return hipErrorInvalidValue;
-    if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, st);
+    if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
+    if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
     switch (epilogue) {
         case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
         case EPI_RESID: return launch_epi<EPI_RESID>(a, cfg, st);

@@ -235,7 +235,127 @@ __device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI>
+// ---- schedule v2: two LONG phases per K-tile (32 MFMAs each) -------------------------------------
+// In-kernel stamps of the 4-phase schedule above (profiles/README.md): each of its 8 barrier intervals
+// per K-tile lasts max(load section 232, MFMA section 289) + ~97 cycles of barrier latency for 256
+// cycles of matrix-pipe work (66 %). Halving the number of intervals halves that fixed cost:
+//     P1(t): read B0, B1, A0(t)   stage A0, A1(t+1) -> other buffer   wait vmcnt(8): A1(t) landed
+//            lgkmcnt(0) | barrier | 32 MFMA: rows i = 0, both column halves | barrier
+//     P2(t): read A1(t)           stage B0, B1(t+2) -> this buffer    wait vmcnt(6): B(t+1), A0(t+1)
+//            lgkmcnt(0) | barrier | 32 MFMA: rows i = 1                  | barrier
+//   (same two wave rows one barrier apart; same LDS image, staging pieces and fragment addresses).
+//   RAW: B(t+1) and A0(t+1) are read in P1(t+1), retired by the vmcnt(6) of P2(t) (the phase before);
+//        A1(t) is read in P2(t), retired by the vmcnt(8) of P1(t). LDS-DMA retires in issue order:
+//        at P1(t)'s wait the queue is [A1(t) x2 | B(t+1) x4 | A(t+1) x4], at P2(t)'s
+//        [B(t+1) x4, A0(t+1) x2 | A1(t+1) x2, B(t+2) x4].
+//   WAR: a half-tile is restaged ONE phase after its last read (B(t+2) in P2(t) over B(t), read in
+//        P1(t)); that is safe only because every wave drains its LDS reads (lgkmcnt(0)) BEFORE the
+//        first barrier of the reading phase, and the other wave row is exactly one barrier behind.
+#define G256_COMPUTE2(I)                                                                         \
+    {                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                         \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                    \
+                    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                             \
+                        acc[I][mf][j][nf] = mma16<SWAP>(Af[mf][kk], Bf[j][nf][kk], acc[I][mf][j][nf]); \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+
+template <bool SWAP>
+__device__ __forceinline__ void g256_mainloop2(const GemmArgs& p, char* smem, int m0, int n0,
+                                               acc256_t& acc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    auto a_off = [&](int i, int g) -> uint32_t {
+        int gm = m0 + g * 128 + i * 64 + srow;
+        gm = gm < p.M ? gm : p.M - 1;   // rows past M read the last row; never stored
+        return (uint32_t)((gm * p.lda + schunk * 8) * 2);
+    };
+    auto b_off = [&](int j, int g) -> uint32_t {
+        const int gn = n0 + (g * 2 + (srow >> 5)) * 64 + j * 32 + (srow & 31);
+        return (uint32_t)((gn * p.ldw + schunk * 8) * 2);
+    };
+    const uint32_t aoff00 = a_off(0, 0), aoff01 = a_off(0, 1), aoff10 = a_off(1, 0), aoff11 = a_off(1, 1);
+    const uint32_t boff00 = b_off(0, 0), boff01 = b_off(0, 1), boff10 = b_off(1, 0), boff11 = b_off(1, 1);
+    const int l15 = lane & 15, q = lane >> 4, sw = (lane >> 1) & 7;
+    const uint32_t a_k0 = (uint32_t)((wr * 64 + l15) * 128 + ((q ^ sw) << 4));
+    const uint32_t b_k0 = (uint32_t)(2 * G256_HALF + (wc * 32 + l15) * 128 + ((q ^ sw) << 4));
+    const char* pa0 = smem + a_k0;
+    const char* pa1 = smem + (a_k0 ^ 64);
+    const char* pb0 = smem + b_k0;
+    const char* pb1 = smem + (b_k0 ^ 64);
+
+    bf16x8_t Af[4][2], Bf[2][2][2];
+    const int nk = p.K >> 6;
+
+    // prologue in the queue order of the steady state: B(0), A(0), then B(1)
+    G256_STAGE_B(0, 0, 0)
+    G256_STAGE_B(1, 0, 0)
+    G256_STAGE_A(0, 0, 0)
+    G256_STAGE_A(1, 0, 0)
+    G256_STAGE_B(0, 1, G256_BUF)
+    G256_STAGE_B(1, 1, G256_BUF)
+    wait_vmcnt<6>();                       // B(0), A0(0) landed; A1(0) and B(1) may still fly
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave row runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    int bo = 0;
+    int kt = 0;
+#define G256_FLIP()                                                           \
+    bo ^= G256_BUF;                                                           \
+    pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);                \
+    pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
+    for (; kt < nk - 2; ++kt) {
+        const int bn = bo ^ G256_BUF;
+        G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)
+        G256_STAGE_A(0, kt + 1, bn)
+        G256_STAGE_A(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE2(0)
+        G256_READ_A(1)
+        G256_STAGE_B(0, kt + 2, bo)
+        G256_STAGE_B(1, kt + 2, bo)
+        wait_vmcnt<6>();
+        G256_COMPUTE2(1)
+        G256_FLIP()
+    }
+    {   // tile nk-2: B(nk) does not exist
+        const int bn = bo ^ G256_BUF;
+        G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)
+        G256_STAGE_A(0, kt + 1, bn)
+        G256_STAGE_A(1, kt + 1, bn)
+        wait_vmcnt<8>();
+        G256_COMPUTE2(0)
+        G256_READ_A(1)
+        wait_vmcnt<2>();                   // B(nk-1), A0(nk-1); A1(nk-1) may still fly
+        G256_COMPUTE2(1)
+        G256_FLIP()
+    }
+    {   // last tile
+        G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)
+        wait_vmcnt<0>();                   // A1
+        G256_COMPUTE2(0)
+        G256_READ_A(1)
+        G256_COMPUTE2(1)
+    }
+#undef G256_FLIP
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of wave row 1
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI, int VER>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N >> 8;
@@ -260,15 +380,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int nf = 0; nf < 2; ++nf) acc[i][mf][j][nf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        g256_mainloop<true>(p, smem, m0, n0, acc);
+        if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
+        else g256_mainloop<true>(p, smem, m0, n0, acc);
         // two passes (i = 0, 1) of 128 rows x 256 f32: row lr = wr*64 + mf*16 + l15 of the pass,
         // 16-B chunk ch of the row stored at ch ^ (lr & 7)
         const int ch_r = tid & 63, n = n0 + ch_r * 4;
         f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __syncthreads();
+        // row `it` (0..15) of pass i that this wave writes out: pass row lr = it*8 + wave
+        auto out_row = [&](int i, int it) { const int lr = it * 8 + wave; return m0 + (lr >> 6) * 128 + i * 64 + (lr & 63); };
+        auto load_addend = [&](int i, int it) -> f32x4_t {
+            const int m = out_row(i, it);
+            const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
+            if constexpr (EPI == EPI_RESID)
+                return *reinterpret_cast<const f32x4_t*>(p.Cf + (size_t)mc * p.ldc + n);
+            else if constexpr (EPI == EPI_F32_POS)
+                return *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n);
+            else
+                return f32x4_t{0.f, 0.f, 0.f, 0.f};
+        };
+        auto stage_pass = [&](int i) {
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
                 const int lr = wr * 64 + mf * 16 + l15;
@@ -281,33 +412,58 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                             acc[i][mf][j][nf];
                     }
             }
+        };
+        if constexpr (VER == 2) {
+            // The residual read-modify-write is HBM traffic (256 KB in + 256 KB out per tile) on top of
+            // a 20 us main loop: the addend loads of a whole pass (16 rows per wave, 64 VGPRs - the
+            // operand fragments are dead) are issued BEFORE the accumulators are staged, and those
+            // of pass 1 before pass 0 is written out, so their latency runs under LDS staging and
+            // the stores instead of in four serial load->wait->store batches.
+            f32x4_t ad0[16], ad1[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) ad0[it] = load_addend(0, it);
+            __syncthreads();
+            stage_pass(0);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) ad1[it] = load_addend(1, it);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int lr = it * 8 + wave, m = out_row(0, it);
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
+                if (m < p.M) *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + ad0[it];
+            }
+            __syncthreads();
+            stage_pass(1);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int lr = it * 8 + wave, m = out_row(1, it);
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
+                if (m < p.M) *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + ad1[it];
+            }
+        } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __syncthreads();
+            stage_pass(i);
             __syncthreads();
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {      // 8 rows per batch: all addend loads first
                 f32x4_t addend[8];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int lr = (hb * 8 + it) * 8 + wave;
-                    const int m = m0 + (lr >> 6) * 128 + i * 64 + (lr & 63);
-                    const int mc = m < p.M ? m : p.M - 1;
-                    if constexpr (EPI == EPI_RESID)
-                        addend[it] = *reinterpret_cast<const f32x4_t*>(p.Cf + (size_t)mc * p.ldc + n);
-                    else if constexpr (EPI == EPI_F32_POS)
-                        addend[it] = *reinterpret_cast<const f32x4_t*>(
-                            p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n);
-                    else
-                        addend[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int it = 0; it < 8; ++it) addend[it] = load_addend(i, hb * 8 + it);
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int lr = (hb * 8 + it) * 8 + wave;
-                    const int m = m0 + (lr >> 6) * 128 + i * 64 + (lr & 63);
+                    const int m = out_row(i, hb * 8 + it);
                     const f32x4_t v =
                         *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
                     if (m < p.M)
                         *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + addend[it];
                 }
             }
+        }
         }
     } else {
         bool v_tile = false;
@@ -317,7 +473,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;   // q * log2(e)/sqrt(64): scores in log2 units
         }
         if (!v_tile) {
-            g256_mainloop<true>(p, smem, m0, n0, acc);
+            if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
+            else g256_mainloop<true>(p, smem, m0, n0, acc);
             // whole tile as [256 rows][512 B]; 8-B chunk c8 of row r stored at c8 ^ ((r & 7) << 1)
             f32x4_t bias4[2][2];
 #pragma unroll
@@ -351,20 +508,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             __syncthreads();
             const int c16 = tid & 31;
+            bf16_t* const obase = (EPI == EPI_QKV) ? p.qk + (size_t)m0 * (2 * p.D) + n0 + c16 * 8
+                                                   : p.Cb + (size_t)m0 * p.ldcb + n0 + c16 * 8;
+            const size_t ostride = (EPI == EPI_QKV) ? (size_t)(2 * p.D) : (size_t)p.ldcb;
+            if (m0 + 256 <= p.M) {
+                // full tile (all but the last row panel): no per-row branch, so the LDS reads of a
+                // batch are all issued before the first store waits for one (the guarded loop below
+                // serialises ds_read -> wait -> store per row)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = (hb * 8 + it) * 16 + (tid >> 5);
+                        v[it] = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c16 ^ (row & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = (hb * 8 + it) * 16 + (tid >> 5);
+                        *reinterpret_cast<uint4*>(obase + (size_t)row * ostride) = v[it];
+                    }
+                }
+            } else {
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 16 + (tid >> 5);
-                if (m0 + row < p.M) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c16 ^ (row & 7)) << 4));
-                    bf16_t* dst = (EPI == EPI_QKV)
-                                      ? p.qk + (size_t)(m0 + row) * (2 * p.D) + n0 + c16 * 8
-                                      : p.Cb + (size_t)(m0 + row) * p.ldcb + n0 + c16 * 8;
-                    *reinterpret_cast<uint4*>(dst) = v;
+                for (int it = 0; it < 16; ++it) {
+                    const int row = it * 16 + (tid >> 5);
+                    if (m0 + row < p.M) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((c16 ^ (row & 7)) << 4));
+                        *reinterpret_cast<uint4*>(obase + (size_t)row * ostride) = v;
+                    }
                 }
             }
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t], t contiguous. Lane = d, registers = 4 tokens.
-            g256_mainloop<false>(p, smem, m0, n0, acc);
+            if constexpr (VER == 2) g256_mainloop2<false>(p, smem, m0, n0, acc);
+            else g256_mainloop<false>(p, smem, m0, n0, acc);
             const int heads = p.D >> 6;
             __syncthreads();
 #pragma unroll
@@ -431,14 +609,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
 template <int EPI>
 hipError_t prepare_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
 }
 
 template <int EPI>
-hipError_t launch_one(const GemmArgs& a, hipStream_t st) {
+hipError_t launch_one(const GemmArgs& a, int ver, hipStream_t st) {
     const int tiles = ((a.M + 255) / 256) * (a.N / 256);
-    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    if (ver == 2) hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    else hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), dim3(tiles), dim3(512), G256_LDS, st, a);
     return hipGetLastError();
 }
 
@@ -455,7 +637,7 @@ hipError_t gemm256_prepare() {
 }
 
 // hipErrorInvalidValue: the shape does not fit this kernel (the caller falls back to k_gemm.hip)
-hipError_t launch_gemm256(const GemmArgs& a, int epilogue, hipStream_t st) {
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st) {
     if (a.M <= 0 || a.N % 256 != 0 || a.K % 64 != 0 || a.K < 128) return hipErrorInvalidValue;
     // 32-bit byte offsets from the operand base pointers
     if ((long long)a.M * a.lda * 2 >= (1ll << 31) || (long long)a.N * a.ldw * 2 >= (1ll << 31))
@@ -479,11 +661,11 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
     switch (epilogue) {
-        case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, st);
-        case EPI_RESID: return launch_one<EPI_RESID>(a, st);
-        case EPI_GELU_BF16: return launch_one<EPI_GELU_BF16>(a, st);
-        case EPI_RELU_BF16: return launch_one<EPI_RELU_BF16>(a, st);
-        case EPI_QKV: return launch_one<EPI_QKV>(a, st);
-        default: return launch_one<EPI_F32>(a, st);
+        case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, ver, st);
+        case EPI_RESID: return launch_one<EPI_RESID>(a, ver, st);
+        case EPI_GELU_BF16: return launch_one<EPI_GELU_BF16>(a, ver, st);
+        case EPI_RELU_BF16: return launch_one<EPI_RELU_BF16>(a, ver, st);
+        case EPI_QKV: return launch_one<EPI_QKV>(a, ver, st);
+        default: return launch_one<EPI_F32>(a, ver, st);
     }
 }

@@ -87,6 +87,12 @@ __device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, fl
     }
     int r, g, b;
     const int sx = px - f.x0, sy = py - f.y0;   // position inside the stored window
+    // inside the frame but outside what the caller stored (a window narrower than the crop): black,
+    // never an out-of-bounds read. The library's own window planner always covers the crop.
+    if ((unsigned)sx >= (unsigned)f.ww || (unsigned)sy >= (unsigned)f.wh) {
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        return;
+    }
     if (f.fmt == VT_PIX_RGB8) {
         const uint8_t* p = f.p0 + (size_t)sy * f.s0 + (size_t)sx * 3;
         r = p[0]; g = p[1]; b = p[2];

@@ -17,8 +17,10 @@ struct FrameDesc {
     const uint8_t* p1;  // NV12 interleaved UV plane
     int32_t w, h, s0, s1, fmt;
     int32_t x0, y0;     // frame coordinates of the first stored pixel (window upload)
+    int32_t ww, wh;     // extent of the stored window in pixels: samples outside it read as black
     int32_t pad;
 };
+static_assert(sizeof(FrameDesc) == 56, "FrameDesc layout");
 
 // per tracked stream, lives in HBM; the decode kernel of frame t writes what the preprocessing
 // kernel of frame t+1 reads, so a stream of updates never needs the host in between.
@@ -77,9 +79,10 @@ int gemm_pick_config(int M, int N, int K, int epilogue);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
 // k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
-#define GEMM_CFG_256P8 17
+#define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
+#define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
 hipError_t gemm256_prepare();
-hipError_t launch_gemm256(const GemmArgs& a, int epilogue, hipStream_t st);
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st);
 
 // y[r] (bf16) = LN(x[in_row(r)]) ; in_row(r) = (r / group) * in_stride + in_off + r % group
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
@@ -90,7 +93,7 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,
                             int H, int npad, hipStream_t st);
 
-// Which attention kernel launch_attention() will run for this shape (env VT_ATTN_MODE overrides),
+// Which attention kernel launch_attention() will run for this shape,
 // and whether it wants Vt with the permuted key order (mode 3). The QKV GEMM that feeds it must be
 // given the same vt_perm.
 int attention_pick_mode(int tokens, int npad);

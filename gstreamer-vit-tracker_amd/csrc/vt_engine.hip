@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -31,9 +32,38 @@ static int set_err(int code, const char* fmt, ...) {
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
         if (_e != hipSuccess)                                                              \
-            return set_err(VT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                           __FILE__, __LINE__);                                            \
+            return set_err(_e == hipErrorOutOfMemory ? VT_ERR_OOM : VT_ERR_HIP,            \
+                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                      \
     } while (0)
+
+// Nothing may unwind across the C boundary (the reference host is built with panic = "abort",
+// /root/reference/Cargo.toml:37): every extern "C" entry is a function-try-block ending in one of
+// these handlers. std::bad_alloc (vector / map / string / new inside the engine) -> VT_ERR_OOM.
+#define VT_NOTHROW_INT                                                                      \
+    catch (const std::bad_alloc&) { return set_err(VT_ERR_OOM, "out of host memory"); }     \
+    catch (const std::exception& ex_) { return set_err(VT_ERR_HIP, "internal error: %s", ex_.what()); } \
+    catch (...) { return set_err(VT_ERR_HIP, "internal error (unknown exception)"); }
+#define VT_NOTHROW_VOID catch (...) { (void)set_err(VT_ERR_HIP, "internal error in a void entry point"); }
+#define VT_NOTHROW_PTR catch (...) { (void)set_err(VT_ERR_HIP, "internal error"); return nullptr; }
+
+// hipSetDevice for the duration of a call, restoring the caller's current device afterwards (a
+// single-process multi-GPU host - or torch in the tests - keeps its own notion of "current").
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define DEVICE_SCOPE(dev)                                                                   \
+    DeviceScope dev_scope_(dev);                                                            \
+    if (dev_scope_.err != hipSuccess)                                                       \
+        return set_err(VT_ERR_HIP, "hipSetDevice(%d): %s", (int)(dev), hipGetErrorString(dev_scope_.err))
 
 // ---- weight blob ---------------------------------------------------------------------------------
 
@@ -77,8 +107,8 @@ struct Profiler {
     }
 };
 
-const char* g_last_gemm_name = "";  // set by launch_gemm_named below
 
+// kernel-family label of a GEMM launch (built only when a profiler is attached)
 static const char* gemm_name(int epi, int M, int N, int K) {
     static const char* tags[] = {"f32pos", "resid", "gelu", "relu", "qkv", "f32"};
     static thread_local char buf[96];
@@ -120,6 +150,7 @@ struct Engine {
     size_t stage_bytes = 0;
     StreamState* h_states_all = nullptr;  // pinned mirror of d_states after the last pass
     int max_w = 3840, max_h = 2160;
+    size_t max_device_bytes = 0;    // vt_config.max_device_mib (0: no limit but free memory)
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
 
@@ -128,6 +159,7 @@ struct Engine {
     int load_blob_host(const std::vector<uint8_t>& blob);
     int load_blob_device(const void* d_src, size_t bytes);
     int index_blob(const uint8_t* host_copy, size_t bytes);
+    size_t activation_bytes() const;
     int alloc_buffers();
     int run_pass(Profiler* prof);
     int capture_graph();
@@ -180,25 +212,46 @@ int Engine::index_blob(const uint8_t* hc, size_t bytes) {
     for (int i = 0; i < 3; ++i) { d.norm_a[i] = fl[i]; d.norm_b[i] = fl[3 + i]; }
     d.success_threshold = fl[6];
     d.ln_eps = fl[7];
-    if (d.patch <= 0 || d.T <= 0 || d.S <= 0 || d.T % d.patch || d.S % d.patch)
-        return set_err(VT_ERR_FORMAT, "weight blob: template/search not multiples of patch");
+    // every dimension is bounded BEFORE anything is derived from it (a corrupt or crafted blob must
+    // not overflow the int arithmetic below or make layers.resize() throw)
+    if (d.patch < 2 || d.patch > 64 || d.T < d.patch || d.S < d.patch || d.T > 4096 || d.S > 4096 ||
+        d.T % d.patch || d.S % d.patch)
+        return set_err(VT_ERR_FORMAT, "weight blob: patch %d / template %d / search %d out of range or "
+                       "not multiples of the patch", d.patch, d.T, d.S);
+    if (d.L < 1 || d.L > 64 || d.D < 128 || d.D > 1536 || d.mlp < 64 || d.mlp > 16384 || d.C < 64 ||
+        d.C > 1024 || d.kpad < 64 || d.kpad > 16384)
+        return set_err(VT_ERR_FORMAT, "weight blob: model dimensions out of range (layers=%d D=%d "
+                       "mlp=%d C=%d kpad=%d)", d.L, d.D, d.mlp, d.C, d.kpad);
     d.gt = d.T / d.patch; d.gs = d.S / d.patch;
     d.nt = d.gt * d.gt; d.ns = d.gs * d.gs; d.ntok = d.nt + d.ns;
     d.npad = (d.ntok + 63) / 64 * 64;
-    if (d.D % 128 || d.H != d.D / 64 || d.mlp % 64 || d.C % 64 || d.kpad % 64 ||
-        d.kpad < 3 * d.patch * d.patch || (d.ntok & 3) || (d.ns & 3) || d.L <= 0 || d.D > 1536)
+    if (d.ntok > 16384)
+        return set_err(VT_ERR_FORMAT, "weight blob: %d tokens per frame (limit 16384)", d.ntok);
+    {   // widths the LayerNorm kernels are instantiated for (k_misc.hip launch_layernorm)
+        const int q = d.D / 128;
+        const bool ln_ok = d.D % 128 == 0 && (q <= 4 || q == 6 || q == 8 || q == 10 || q == 12);
+        if (!ln_ok)
+            return set_err(VT_ERR_FORMAT, "weight blob: embedding width D=%d is not supported (LayerNorm "
+                           "kernels exist for D in {128, 256, 384, 512, 768, 1024, 1280, 1536})", d.D);
+    }
+    if (d.H != d.D / 64 || d.mlp % 64 || d.C % 64 || d.kpad % 64 ||
+        d.kpad < 3 * d.patch * d.patch || (d.ntok & 3) || (d.ns & 3))
         return set_err(VT_ERR_FORMAT, "weight blob: unsupported model shape (D=%d H=%d mlp=%d C=%d "
                        "kpad=%d tokens=%d)", d.D, d.H, d.mlp, d.C, d.kpad, d.ntok);
-    if (n_tensors <= 0 || kHeaderBytes + (size_t)n_tensors * kEntryBytes > bytes)
+    if (n_tensors <= 0 || n_tensors > 4096 || kHeaderBytes + (size_t)n_tensors * kEntryBytes > bytes)
         return set_err(VT_ERR_FORMAT, "weight blob: tensor table out of range");
+    const uint64_t table_end = kHeaderBytes + (uint64_t)n_tensors * kEntryBytes;
     tens.clear();
     for (int i = 0; i < n_tensors; ++i) {
         BlobEntry e;
         memcpy(&e, hc + kHeaderBytes + (size_t)i * kEntryBytes, sizeof(e));
         e.name[31] = 0;
-        const size_t esz = e.dtype == 1 ? 2 : 4;
-        if (e.dtype > 1 || e.offset % 16 || e.offset + e.nbytes > bytes ||
-            e.nbytes != (uint64_t)e.rows * e.cols * esz)
+        const uint64_t esz = e.dtype == 1 ? 2 : 4;
+        // offset/nbytes checked without forming offset + nbytes (which wraps for offset near 2^64);
+        // data may not overlap the header or the table
+        if (e.dtype > 1 || e.offset % 16 || e.offset < table_end || e.offset > bytes ||
+            e.nbytes > bytes - e.offset || e.rows == 0 || e.cols == 0 || e.rows > (1u << 20) ||
+            e.cols > (1u << 20) || e.nbytes != (uint64_t)e.rows * e.cols * esz)
             return set_err(VT_ERR_FORMAT, "weight blob: tensor '%s' malformed", e.name);
         TensorRef r;
         r.ptr = d_blob + e.offset;
@@ -278,8 +331,27 @@ static hipError_t dalloc0(T** p, size_t count) {
     return hipMemset(*p, 0, count * sizeof(T));
 }
 
+// HBM the activations of B streams need (bytes), as alloc_buffers() lays them out
+size_t Engine::activation_bytes() const {
+    const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
+    return 2 * (M * d.kpad + M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
+                Ms * d.D + 2 * Ms * d.C + Ms * 9 * d.C) +
+           4 * (M * d.D + Ms * 8) + (size_t)B * (sizeof(StreamState) + sizeof(FrameDesc) + sizeof(vt_result));
+}
+
 int Engine::alloc_buffers() {
     const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
+    {   // fail early and cleanly (VT_ERR_OOM) instead of half-way through a dozen hipMallocs
+        const size_t need = activation_bytes();
+        if (max_device_bytes && need + blob_bytes > max_device_bytes)
+            return set_err(VT_ERR_OOM, "%d streams need %.1f MiB of HBM (+ %.1f MiB of weights); "
+                           "vt_config.max_device_mib allows %.1f", B, need / 1048576.0,
+                           blob_bytes / 1048576.0, max_device_bytes / 1048576.0);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b)
+            return set_err(VT_ERR_OOM, "%d streams need %.1f MiB of HBM for activations; %.1f MiB "
+                           "are free on device %d", B, need / 1048576.0, free_b / 1048576.0, device);
+    }
     HIPCHK(dalloc0(&d_patches, M * d.kpad));
     HIPCHK(dalloc0(&d_x, M * d.D));
     HIPCHK(dalloc0(&d_ln, M * d.D));
@@ -343,7 +415,7 @@ int Engine::run_pass(Profiler* prof) {
         const double fl = 2.0 * a.M * a.N * a.K;
         const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                           (epi == EPI_RESID || epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
-        L(gemm_name(epi, a.M, a.N, a.K), fl, by, [&] { return launch_gemm(a, epi, stream); });
+        L(prof ? gemm_name(epi, a.M, a.N, a.K) : "", fl, by, [&] { return launch_gemm(a, epi, stream); });
     };
     auto tap = [&](int slot) {
         if (taps && lerr == hipSuccess)
@@ -469,30 +541,50 @@ int Engine::capture_graph() {
 static int check_frame(const vt_frame& f) {
     if (!f.plane0 || f.width < 16 || f.height < 16 || f.width > 16384 || f.height > 16384)
         return set_err(VT_ERR_INVALID_ARG, "frame: null plane or size out of range");
-    const bool window = f.origin_x != 0 || f.origin_y != 0 || f.reserved == 1;  // strides cover the window only
-    if (f.format == VT_PIX_RGB8) {
-        if (f.stride0 < (window ? 6 : f.width * 3)) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
-    } else if (f.format == VT_PIX_NV12) {
-        if (!f.plane1 || f.stride0 < (window ? 2 : f.width) || f.stride1 < (window ? 2 : ((f.width + 1) & ~1)))
-            return set_err(VT_ERR_INVALID_ARG, "nv12: null UV plane or stride too small");
-    } else if (f.format == VT_PIX_YUY2) {
-        if ((f.width & 1) || f.stride0 < (window ? 4 : f.width * 2))
-            return set_err(VT_ERR_INVALID_ARG, "yuy2: odd width or stride < 2*width");
-    } else {
+    if (f.format != VT_PIX_RGB8 && f.format != VT_PIX_NV12 && f.format != VT_PIX_YUY2)
         return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", f.format);
-    }
+    const bool window = f.origin_x != 0 || f.origin_y != 0 || f.windowed == 1;
     if (f.origin_x < 0 || f.origin_y < 0 || f.origin_x >= f.width || f.origin_y >= f.height ||
         (f.format == VT_PIX_NV12 && ((f.origin_x | f.origin_y) & 1)) ||
         (f.format == VT_PIX_YUY2 && (f.origin_x & 1)))
         return set_err(VT_ERR_INVALID_ARG, "frame window origin %d,%d invalid", f.origin_x, f.origin_y);
+    // extent of what the planes hold: the kernels never read outside it (fetch_rgb, k_preproc.hip)
+    int ww = f.width, wh = f.height;
+    (void)wh;
+    if (window) {
+        if (f.window_w < 1 || f.window_h < 1 || f.window_w > f.width - f.origin_x ||
+            f.window_h > f.height - f.origin_y)
+            return set_err(VT_ERR_INVALID_ARG, "windowed frame needs window_w/window_h inside the frame "
+                           "(got %dx%d at %d,%d of %dx%d)", f.window_w, f.window_h, f.origin_x, f.origin_y,
+                           f.width, f.height);
+        ww = f.window_w; wh = f.window_h;
+        if (f.format == VT_PIX_NV12 && (((ww & 1) && f.origin_x + ww != f.width) ||
+                                        ((wh & 1) && f.origin_y + wh != f.height)))
+            return set_err(VT_ERR_INVALID_ARG, "nv12 window extent must be even unless it ends at the frame edge");
+    } else if (f.window_w != 0 || f.window_h != 0) {
+        if (f.window_w != f.width || f.window_h != f.height)
+            return set_err(VT_ERR_INVALID_ARG, "window_w/window_h set on a frame that is not windowed");
+    }
+    if (f.format == VT_PIX_RGB8) {
+        if (f.stride0 < ww * 3) return set_err(VT_ERR_INVALID_ARG, "rgb8 stride < 3*width");
+    } else if (f.format == VT_PIX_NV12) {
+        if (!f.plane1 || f.stride0 < ww || f.stride1 < ((ww + 1) & ~1))
+            return set_err(VT_ERR_INVALID_ARG, "nv12: null UV plane or stride too small");
+    } else {
+        if ((f.width & 1) || f.stride0 < ((ww + 1) & ~1) * 2)
+            return set_err(VT_ERR_INVALID_ARG, "yuy2: odd width or stride < 2*width");
+    }
     return VT_OK;
 }
 
 static void to_desc(const vt_frame& f, FrameDesc* o) {
+    const bool window = f.origin_x != 0 || f.origin_y != 0 || f.windowed == 1;
     o->p0 = (const uint8_t*)f.plane0;
     o->p1 = (const uint8_t*)f.plane1;
     o->w = f.width; o->h = f.height; o->s0 = f.stride0; o->s1 = f.stride1; o->fmt = f.format;
     o->x0 = f.origin_x; o->y0 = f.origin_y;
+    o->ww = window ? f.window_w : f.width;
+    o->wh = window ? f.window_h : f.height;
     o->pad = 0;
 }
 
@@ -503,7 +595,7 @@ int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
         box.x < -32768 || box.y < -32768 || box.x > 32768 || box.y > 32768)
         return set_err(VT_ERR_INVALID_ARG, "init: bbox %d,%d %dx%d out of range", box.x, box.y,
                        box.width, box.height);
-    HIPCHK(hipSetDevice(device));
+    DEVICE_SCOPE(device);
     HIPCHK(hipStreamSynchronize(stream));
     memset(h_state, 0, sizeof(StreamState));
     h_state->box[0] = (float)box.x; h_state->box[1] = (float)box.y;
@@ -527,7 +619,7 @@ int Engine::enqueue(const vt_frame* frames, int n) {
         if (!h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d: update before init", b);
         if (int rc = check_frame(frames[b])) return rc;
     }
-    HIPCHK(hipSetDevice(device));
+    DEVICE_SCOPE(device);
     const int slot = ring_pos;
     ring_pos = (ring_pos + 1) % RING;
     HIPCHK(hipEventSynchronize(ring_ev[slot]));  // the copy that last used this slot is done
@@ -546,7 +638,7 @@ int Engine::enqueue(const vt_frame* frames, int n) {
 
 int Engine::wait(vt_result* out, int n) {
     if (n > B) n = B;
-    HIPCHK(hipSetDevice(device));
+    DEVICE_SCOPE(device);
     HIPCHK(hipStreamSynchronize(stream));
     if (out)
         for (int b = 0; b < n; ++b) out[b] = h_results[b];
@@ -590,9 +682,10 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
                        const vt_config* cfg, int B, Engine** out) {
     if (!out) return set_err(VT_ERR_INVALID_ARG, "null output handle");
     *out = nullptr;
-    if (B < 1 || B > 4096) return set_err(VT_ERR_INVALID_ARG, "n_streams %d out of range", B);
+    if (B < 1 || B > VT_MAX_STREAMS)
+        return set_err(VT_ERR_INVALID_ARG, "n_streams %d out of range (1..%d)", B, VT_MAX_STREAMS);
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     Engine* e = new (std::nothrow) Engine();
     if (!e) return set_err(VT_ERR_OOM, "out of host memory");
@@ -615,6 +708,7 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
             e->use_graph = cfg->use_graph != 0;
             if (cfg->max_frame_width > 0) e->max_w = cfg->max_frame_width;
             if (cfg->max_frame_height > 0) e->max_h = cfg->max_frame_height;
+            if (cfg->max_device_mib > 0) e->max_device_bytes = (size_t)cfg->max_device_mib << 20;
         }
         if ((rc = e->alloc_buffers())) break;
     } while (0);
@@ -643,21 +737,21 @@ static void fill_info(const Engine* e, vt_model_info* o) {
 // ---- C ABI ---------------------------------------------------------------------------------------
 
 struct vt_group { Engine* e; };
-struct vt_tracker { Engine* e; };
+struct vt_tracker { Engine* e; vt_group view; };   // view: the tracker as a group of one
 
 extern "C" {
 
-void vt_config_default(vt_config* cfg) {
+void vt_config_default(vt_config* cfg) try {
     if (!cfg) return;
     memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = sizeof(vt_config);
     cfg->success_threshold = -1.0f;
     cfg->use_graph = 1;
     cfg->n_streams = 1;
-}
+} VT_NOTHROW_VOID
 const char* vt_last_error(void) { return g_err; }
 int vt_abi_version(void) { return VT_ABI_VERSION; }
-int vt_device_count(void) {
+int vt_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     int ok = 0;
@@ -666,18 +760,18 @@ int vt_device_count(void) {
         if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
     }
     return ok;
-}
+} VT_NOTHROW_INT
 
 struct vt_extmem {
     int device;
     hipExternalMemory_t mem;
 };
 
-int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr) {
+int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr) try {
     if (!out || !d_ptr || fd < 0 || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     *out = nullptr; *d_ptr = nullptr;
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     const int dupfd = dup(fd);     // the import takes the descriptor over; the caller keeps its own
     if (dupfd < 0) return set_err(VT_ERR_INVALID_ARG, "dup(fd) failed");
     hipExternalMemoryHandleDesc hd;
@@ -700,24 +794,26 @@ int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void*
         (void)hipDestroyExternalMemory(mem);
         return set_err(VT_ERR_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(he));
     }
-    *out = new vt_extmem{device_id, mem};
+    vt_extmem* xm = new (std::nothrow) vt_extmem{device_id, mem};
+    if (!xm) { (void)hipDestroyExternalMemory(mem); return set_err(VT_ERR_OOM, "out of host memory"); }
+    *out = xm;
     *d_ptr = p;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
-void vt_release_dmabuf(vt_extmem* m) {
+void vt_release_dmabuf(vt_extmem* m) try {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
     (void)hipDestroyExternalMemory(m->mem);
     delete m;
-}
+} VT_NOTHROW_VOID
 
-int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out) {
+int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out) try {
     if (!d_ptr || !fd_out || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     *fd_out = -1;
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     int fd = -1;
     hipError_t he = hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)d_ptr, bytes,
                                                    hipMemRangeHandleTypeDmaBufFd, 0);
@@ -725,9 +821,9 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
         return set_err(VT_ERR_HIP, "hipMemGetHandleForAddressRange(dma-buf): %s", hipGetErrorString(he));
     *fd_out = fd;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
-int vt_recommended_streams(const vt_model_info* info, int max_streams) {
+int vt_recommended_streams(const vt_model_info* info, int max_streams) try {
     if (!info || info->dim <= 0 || (info->dim % 256) != 0 || max_streams < 1) return 1;
     const long tokens = (long)info->tokens_template + info->tokens_search;
     const long cols[3] = {info->dim / 256, 3L * info->dim / 256, info->mlp_dim / 256};
@@ -741,76 +837,80 @@ int vt_recommended_streams(const vt_model_info* info, int max_streams) {
         if (ok) return b;
     }
     return 1;
-}
+} VT_NOTHROW_INT
 
-int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out) {
+int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out) try {
     if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;
     const int B = (cfg && cfg->struct_size >= sizeof(vt_config) && cfg->n_streams > 0) ? cfg->n_streams : 1;
     if (int rc = make_engine(weights_path, nullptr, 0, device_id, cfg, B, &e)) return rc;
-    *out = new vt_group{e};
+    vt_group* g = new (std::nothrow) vt_group{e};
+    if (!g) { delete e; return set_err(VT_ERR_OOM, "out of host memory"); }
+    *out = g;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 int vt_group_create_from_device_blob(const void* d_blob, size_t bytes, int device_id,
-                                     const vt_config* cfg, vt_group** out) {
+                                     const vt_config* cfg, vt_group** out) try {
     if (!d_blob || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;
     const int B = (cfg && cfg->struct_size >= sizeof(vt_config) && cfg->n_streams > 0) ? cfg->n_streams : 1;
     if (int rc = make_engine(nullptr, d_blob, bytes, device_id, cfg, B, &e)) return rc;
-    *out = new vt_group{e};
+    vt_group* g = new (std::nothrow) vt_group{e};
+    if (!g) { delete e; return set_err(VT_ERR_OOM, "out of host memory"); }
+    *out = g;
     return VT_OK;
-}
-void vt_group_destroy(vt_group* g) {
+} VT_NOTHROW_INT
+void vt_group_destroy(vt_group* g) try {
     if (!g) return;
     delete g->e;
     delete g;
-}
+} VT_NOTHROW_VOID
 int vt_group_streams(const vt_group* g) { return g ? g->e->B : 0; }
-int vt_group_get_model_info(const vt_group* g, vt_model_info* out) {
+int vt_group_get_model_info(const vt_group* g, vt_model_info* out) try {
     if (!g || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     fill_info(g->e, out);
     return VT_OK;
-}
-int vt_group_init_device(vt_group* g, int stream, const vt_frame* frame, vt_bbox box) {
+} VT_NOTHROW_INT
+int vt_group_init_device(vt_group* g, int stream, const vt_frame* frame, vt_bbox box) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     return g->e->init_stream(stream, frame, box);
-}
-int vt_group_enqueue_device(vt_group* g, const vt_frame* frames, int n) {
+} VT_NOTHROW_INT
+int vt_group_enqueue_device(vt_group* g, const vt_frame* frames, int n) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     return g->e->enqueue(frames, n);
-}
-int vt_group_wait(vt_group* g, vt_result* out, int n) {
+} VT_NOTHROW_INT
+int vt_group_wait(vt_group* g, vt_result* out, int n) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     return g->e->wait(out, n);
-}
-int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out) {
+} VT_NOTHROW_INT
+int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     if (int rc = g->e->enqueue(frames, n)) return rc;
     return g->e->wait(out, n);
-}
+} VT_NOTHROW_INT
 void* vt_group_hip_stream(vt_group* g) { return g ? (void*)g->e->stream : nullptr; }
 
 static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float (*boxes)[4], vt_frame* dev);
 
-int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box) {
+int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box) try {
     if (!g || !host_frame) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = g->e;
     if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));     // the staging arena is shared by the group's passes
     const float fb[1][4] = {{(float)box.x, (float)box.y, (float)box.width, (float)box.height}};
     vt_frame f;
     if (int rc = stage_host_frames(e, host_frame, 1, fb, &f)) return rc;
     return e->init_stream(stream, &f, box);
-}
+} VT_NOTHROW_INT
 
-int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out) {
+int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out) try {
     if (!g || !host_frames || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = g->e;
     if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "update_host: need exactly %d frames", e->B);
     for (int b = 0; b < n; ++b)
         if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));     // last pass done: its boxes are in h_states_all
     std::vector<vt_frame> dev((size_t)n);
     std::vector<float> boxes((size_t)n * 4);
@@ -819,40 +919,45 @@ int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_res
         return rc;
     if (int rc = e->enqueue(dev.data(), n)) return rc;
     return e->wait(out, n);
-}
+} VT_NOTHROW_INT
 
-int vt_group_enable_taps(vt_group* g, int enable) {
+int vt_group_enable_taps(vt_group* g, int enable) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
     Engine* e = g->e;
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (enable && !e->d_taps)
         HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * e->B * e->d.ntok * e->d.D));
     e->taps = enable != 0;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
-int vt_group_set_state_box(vt_group* g, int stream, const float* box4) {
+int vt_group_set_state_box(vt_group* g, int stream, const float* box4) try {
     if (!g || !box4) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = g->e;
     if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
     if (!e->h_initialized[stream]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", stream);
-    if (!(box4[2] >= 1.0f) || !(box4[3] >= 1.0f)) return set_err(VT_ERR_INVALID_ARG, "box size < 1");
-    HIPCHK(hipSetDevice(e->device));
+    for (int k = 0; k < 4; ++k)
+        if (!std::isfinite(box4[k])) return set_err(VT_ERR_INVALID_ARG, "state box: non-finite value");
+    if (!(box4[2] >= 1.0f) || !(box4[3] >= 1.0f) || box4[2] > 32768.0f || box4[3] > 32768.0f ||
+        fabsf(box4[0]) > 65536.0f || fabsf(box4[1]) > 65536.0f)
+        return set_err(VT_ERR_INVALID_ARG, "state box %g,%g %gx%g out of range", box4[0], box4[1],
+                       box4[2], box4[3]);
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->d_states[stream].box, box4, 4 * sizeof(float), hipMemcpyHostToDevice));
     memcpy(e->h_states_all[stream].box, box4, 4 * sizeof(float));
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iters,
-                            vt_kernel_time* out, int max_out) {
+                            vt_kernel_time* out, int max_out) try {
     if (!g || !frames || !out || iters < 1) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     Engine* e = g->e;
     if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "profile: need exactly %d frames", e->B);
     for (int b = 0; b < e->B; ++b)
         if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     FrameDesc* hf = e->h_frames;
     for (int b = 0; b < e->B; ++b) {
@@ -883,7 +988,7 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
         o.bytes = f.bytes / iters;
     }
     return k;
-}
+} VT_NOTHROW_INT
 
 static int64_t copy_out_f32(const float* dsrc, int64_t count, float* out, int64_t cap) {
     if (!out) return count;
@@ -905,11 +1010,12 @@ static int64_t copy_out_bf16(const bf16_t* dsrc, int64_t count, float* out, int6
     return count;
 }
 
-int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* out, int64_t capacity) {
+int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* out, int64_t capacity) try {
     if (!g || !name) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = g->e;
     if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
-    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+    DEVICE_SCOPE(e->device);
+    if (hipStreamSynchronize(e->stream) != hipSuccess)
         return set_err(VT_ERR_HIP, "read_tensor: sync failed");
     const ModelDims& d = e->d;
     const std::string n(name);
@@ -933,35 +1039,39 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
         return copy_out_f32(e->d_taps + ((size_t)slot * M + b * d.ntok) * d.D, (int64_t)d.ntok * d.D, out, capacity);
     }
     return set_err(VT_ERR_INVALID_ARG, "unknown tensor '%s'", name);
-}
+} VT_NOTHROW_INT
 
 // ---- single-stream drop-in --------------------------------------------------------------------------
 
-int vt_create(const char* weights_path, int device_id, const vt_config* cfg, vt_tracker** out) {
+int vt_create(const char* weights_path, int device_id, const vt_config* cfg, vt_tracker** out) try {
     if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;
     if (int rc = make_engine(weights_path, nullptr, 0, device_id, cfg, 1, &e)) return rc;
-    *out = new vt_tracker{e};
+    vt_tracker* t = new (std::nothrow) vt_tracker{e, {e}};
+    if (!t) { delete e; return set_err(VT_ERR_OOM, "out of host memory"); }
+    *out = t;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 int vt_create_from_device_blob(const void* d_blob, size_t bytes, int device_id, const vt_config* cfg,
-                               vt_tracker** out) {
+                               vt_tracker** out) try {
     if (!d_blob || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;
     if (int rc = make_engine(nullptr, d_blob, bytes, device_id, cfg, 1, &e)) return rc;
-    *out = new vt_tracker{e};
+    vt_tracker* t = new (std::nothrow) vt_tracker{e, {e}};
+    if (!t) { delete e; return set_err(VT_ERR_OOM, "out of host memory"); }
+    *out = t;
     return VT_OK;
-}
-void vt_destroy(vt_tracker* t) {
+} VT_NOTHROW_INT
+void vt_destroy(vt_tracker* t) try {
     if (!t) return;
     delete t->e;
     delete t;
-}
-int vt_get_model_info(const vt_tracker* t, vt_model_info* out) {
+} VT_NOTHROW_VOID
+int vt_get_model_info(const vt_tracker* t, vt_model_info* out) try {
     if (!t || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     fill_info(t->e, out);
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 // Host-pointer ingest: only the window of the frame that the call can sample is uploaded. The
 // reference hands over the whole frame (6.2 MB of RGB8 at 1080p, src/pipeline.rs:105-112) although
@@ -1024,7 +1134,7 @@ static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_
 // pinned + device arena of at least `need` bytes (grown with the stream idle)
 static int ensure_stage(Engine* e, size_t need) {
     if (need <= e->stage_bytes) return VT_OK;
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->d_stage) { (void)hipFree(e->d_stage); e->d_stage = nullptr; }
     if (e->h_pack) { (void)hipHostFree(e->h_pack); e->h_pack = nullptr; }
@@ -1041,7 +1151,8 @@ static void pack_window(Engine* e, const HostWin& wn, size_t off, vt_frame* f) {
     memset(f, 0, sizeof(*f));
     f->width = wn.w; f->height = wn.h; f->format = wn.fmt;
     f->origin_x = wn.x_lo; f->origin_y = wn.y_lo;
-    f->reserved = 1;   // strides describe the packed window
+    f->windowed = 1;   // strides describe the packed window
+    f->window_w = wn.ww; f->window_h = wn.wh;
     if (wn.fmt == VT_PIX_RGB8 || wn.fmt == VT_PIX_YUY2) {
         const size_t bpp = wn.fmt == VT_PIX_RGB8 ? 3 : 2;
         const size_t rb = (size_t)wn.ww * bpp;
@@ -1075,7 +1186,7 @@ static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float
         total += wins[i].bytes;
     }
     if (int rc = ensure_stage(e, total)) return rc;
-    HIPCHK(hipSetDevice(e->device));
+    DEVICE_SCOPE(e->device);
     // the previous call's copy out of the pinned arena has finished: every host entry point waits
     // for its pass before returning
     size_t off = 0;
@@ -1104,50 +1215,50 @@ static int do_update(vt_tracker* t, const vt_frame* f, vt_result* out) {
     return t->e->wait(out, 1);
 }
 
-int vt_init_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_bbox box) {
+int vt_init_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_bbox box) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f;
     const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
     if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, fb, &f)) return rc;
     return do_init(t, &f, box);
-}
-int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_result* out) {
+} VT_NOTHROW_INT
+int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_bytes, vt_result* out) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
     if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
-}
-int vt_init_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_bbox box) {
+} VT_NOTHROW_INT
+int vt_init_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_bbox box) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f;
     const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
     if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, fb, &f)) return rc;
     return do_init(t, &f, box);
-}
-int vt_update_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_result* out) {
+} VT_NOTHROW_INT
+int vt_update_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_result* out) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
     if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
-}
+} VT_NOTHROW_INT
 int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
-                 int uv_stride, vt_bbox box) {
+                 int uv_stride, vt_bbox box) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f;
     const float fb[4] = {(float)box.x, (float)box.y, (float)box.width, (float)box.height};
     if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, fb, &f)) return rc;
     return do_init(t, &f, box);
-}
+} VT_NOTHROW_INT
 int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
-                   int uv_stride, vt_result* out) {
+                   int uv_stride, vt_result* out) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
     if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, t->e->h_states_all[0].box, &f)) return rc;
     return do_update(t, &f, out);
-}
+} VT_NOTHROW_INT
 
 static vt_frame dev_frame(int fmt, const void* p0, const void* p1, int w, int h, int s0, int s1) {
     vt_frame f;
@@ -1156,36 +1267,33 @@ static vt_frame dev_frame(int fmt, const void* p0, const void* p1, int w, int h,
     f.format = fmt;
     return f;
 }
-int vt_init_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_bbox box) {
+int vt_init_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_bbox box) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f = dev_frame(VT_PIX_RGB8, d_rgb, nullptr, w, h, stride_bytes, 0);
     return do_init(t, &f, box);
-}
-int vt_update_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_result* out) {
+} VT_NOTHROW_INT
+int vt_update_rgb8_device(vt_tracker* t, const void* d_rgb, int w, int h, int stride_bytes, vt_result* out) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f = dev_frame(VT_PIX_RGB8, d_rgb, nullptr, w, h, stride_bytes, 0);
     return do_update(t, &f, out);
-}
+} VT_NOTHROW_INT
 int vt_init_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h, int y_stride,
-                        int uv_stride, vt_bbox box) {
+                        int uv_stride, vt_bbox box) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f = dev_frame(VT_PIX_NV12, d_y, d_uv, w, h, y_stride, uv_stride);
     return do_init(t, &f, box);
-}
+} VT_NOTHROW_INT
 int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h, int y_stride,
-                          int uv_stride, vt_result* out) {
+                          int uv_stride, vt_result* out) try {
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     vt_frame f = dev_frame(VT_PIX_NV12, d_y, d_uv, w, h, y_stride, uv_stride);
     return do_update(t, &f, out);
-}
+} VT_NOTHROW_INT
 
 // a single tracker viewed as a group of one (taps, profiling, stream handle)
-vt_group* vt_tracker_as_group(vt_tracker* t) {
-    static thread_local vt_group view;
-    if (!t) return nullptr;
-    view.e = t->e;
-    return &view;
-}
+vt_group* vt_tracker_as_group(vt_tracker* t) try {
+    return t ? &t->view : nullptr;   // owned by the tracker: two trackers never share a view
+} VT_NOTHROW_PTR
 
 // ---- reference colour converter ------------------------------------------------------------------------
 
@@ -1197,10 +1305,10 @@ static size_t nv12_bytes_read(size_t w, size_t h) {
 }
 
 int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w, int h, void* d_rgb_out,
-                           void* hip_stream) {
+                           void* hip_stream) try {
     if (!d_nv12 || !d_rgb_out || w <= 0 || h <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     hipStream_t st = (hipStream_t)hip_stream;
     if (len < (size_t)w * h * 3 / 2) {  // src/nv12_convert.rs:48-50: short buffer -> zero frame
         HIPCHK(hipMemsetAsync(d_rgb_out, 0, (size_t)w * h * 3, st));
@@ -1211,12 +1319,12 @@ int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w,
                        "conversion of a %dx%d frame reads", len, nv12_bytes_read(w, h), w, h);
     HIPCHK(launch_nv12_to_rgb8((const uint8_t*)d_nv12, w, h, (uint8_t*)d_rgb_out, st));
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
-int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h, uint8_t* rgb_out) {
+int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h, uint8_t* rgb_out) try {
     if (!nv12 || !rgb_out || w <= 0 || h <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     const size_t out_bytes = (size_t)w * h * 3;
     if (len < (size_t)w * h * 3 / 2) {
         memset(rgb_out, 0, out_bytes);
@@ -1236,7 +1344,7 @@ int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h
     (void)hipFree(din);
     (void)hipFree(dout);
     return rc;
-}
+} VT_NOTHROW_INT
 
 struct DevBuf {
     void* p = nullptr;
@@ -1253,7 +1361,7 @@ static int overlay_device(int device_id, void* d_surf, int width, int height, in
     if (n == 0) return VT_OK;
     if (n > 256) return set_err(VT_ERR_INVALID_ARG, "at most 256 draw commands per call");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     hipStream_t st = (hipStream_t)hip_stream;
     vt_draw_cmd* d_cmds = nullptr;
     HIPCHK(hipMallocAsync((void**)&d_cmds, sizeof(vt_draw_cmd) * n, st));
@@ -1271,7 +1379,7 @@ static int overlay_host(int device_id, uint8_t* surf, size_t bytes, int width, i
                         const vt_draw_cmd* cmds, int n, bool rgb) {
     if (!surf || width <= 0 || height <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     DevBuf d;
     HIPCHK(d.alloc(bytes));
     HIPCHK(hipMemcpy(d.p, surf, bytes, hipMemcpyHostToDevice));
@@ -1282,28 +1390,28 @@ static int overlay_host(int device_id, uint8_t* surf, size_t bytes, int width, i
 }
 
 int vt_overlay_nv12_device(int device_id, void* d_y, int width, int height, int stride, const vt_draw_cmd* cmds,
-                           int n, void* hip_stream) {
+                           int n, void* hip_stream) try {
     return overlay_device(device_id, d_y, width, height, stride, width, cmds, n, hip_stream, false);
-}
-int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds, int n) {
+} VT_NOTHROW_INT
+int vt_overlay_nv12(int device_id, uint8_t* nv12, int width, int height, const vt_draw_cmd* cmds, int n) try {
     return overlay_host(device_id, nv12, (size_t)width * height, width, height, width, cmds, n, false);
-}
+} VT_NOTHROW_INT
 int vt_overlay_rgb8_device(int device_id, void* d_rgb, int width, int height, int stride, const vt_draw_cmd* cmds,
-                           int n, void* hip_stream) {
+                           int n, void* hip_stream) try {
     return overlay_device(device_id, d_rgb, width, height, stride, width * 3, cmds, n, hip_stream, true);
-}
-int vt_overlay_rgb8(int device_id, uint8_t* rgb, int width, int height, const vt_draw_cmd* cmds, int n) {
+} VT_NOTHROW_INT
+int vt_overlay_rgb8(int device_id, uint8_t* rgb, int width, int height, const vt_draw_cmd* cmds, int n) try {
     return overlay_host(device_id, rgb, (size_t)width * height * 3, width, height, width * 3, cmds, n, true);
-}
+} VT_NOTHROW_INT
 
 // ---- operator-level entry points ---------------------------------------------------------------------------
 
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* c_inout,
-                    int M, int N, int K, int epilogue) {
+                    int M, int N, int K, int epilogue, int cfg) try {
     if (!a || !w || !c_inout || M <= 0 || N <= 0 || K <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (N % 64 || K % 64) return set_err(VT_ERR_INVALID_ARG, "gemm: N and K must be multiples of 64");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     DevBuf da, dw, db, dc, dcb;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
@@ -1324,7 +1432,9 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
         case 3: epi = EPI_RELU_BF16; break;
         default: return set_err(VT_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
-    HIPCHK(launch_gemm(g, epi, nullptr));
+    if (cfg < 0) HIPCHK(launch_gemm(g, epi, nullptr));
+    else if (launch_gemm_cfg(g, epi, cfg, nullptr) != hipSuccess)
+        return set_err(VT_ERR_INVALID_ARG, "gemm: tile configuration %d does not fit M=%d N=%d K=%d", cfg, M, N, K);
     HIPCHK(hipDeviceSynchronize());
     if (epi == EPI_F32 || epi == EPI_RESID) {
         HIPCHK(hipMemcpy(c_inout, dc.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -1337,15 +1447,15 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
         }
     }
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 // Timing helper for kernel tuning: runs the GEMM kernel `iters` times on device-resident random
 // operands with tile configuration `cfg` (<0: the launcher's own choice) and returns the mean time
 // per launch in microseconds (HIP events on the null stream).
-int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters, float* us_out) {
+int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters, float* us_out) try {
     if (M <= 0 || N % 64 || K % 64 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dc, dcb, dvt;
@@ -1370,11 +1480,13 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     if (cfg < 0) cfg = gemm_pick_config(M, N, K, epilogue);
     DevBuf ddbg;
     const size_t dbg_words = (size_t)((M + 63) / 64) * (N / 64) * 8 * 4;
-    if (getenv("VT_STAMPS_DUMP")) {
-        HIPCHK(ddbg.alloc(dbg_words * 8));
-        HIPCHK(hipMemset(ddbg.p, 0, dbg_words * 8));
-        g.dbg = (unsigned long long*)ddbg.p;
-    }
+#ifdef VT_STAMPS   // diagnostic builds only: per-wave cycle sums of the main loop
+    HIPCHK(ddbg.alloc(dbg_words * 8));
+    HIPCHK(hipMemset(ddbg.p, 0, dbg_words * 8));
+    g.dbg = (unsigned long long*)ddbg.p;
+#else
+    (void)dbg_words;
+#endif
     for (int i = 0; i < 3; ++i) HIPCHK(launch_gemm_cfg(g, epilogue, cfg, nullptr));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1397,15 +1509,15 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
                        cfg, n, s[0] / n, s[1] / n, s[2] / n, s[3] / n);
     }
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* qk_out,
-                   float* vt_out, int B, int tokens, int D) {
+                   float* vt_out, int B, int tokens, int D, int cfg, int vt_perm) try {
     // QKV GEMM with the attention-layout epilogue: qk_out [B*tokens][2D], vt_out [B*H][64][npad]
     if (!a || !w || !bias || !qk_out || !vt_out || B <= 0 || tokens <= 0 || D % 64 || (tokens & 3))
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     const int M = B * tokens, H = D / 64, npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dqk, dvt;
@@ -1418,8 +1530,10 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = D; g.W = (const bf16_t*)dw.p; g.ldw = D; g.bias = (const float*)db.p;
     g.M = M; g.N = 3 * D; g.K = D; g.qk = (bf16_t*)dqk.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
-    g.vt_perm = (getenv("VT_QKV_PERM") && atoi(getenv("VT_QKV_PERM"))) ? 1 : 0;   // tests: the mode-3 attention layout
-    HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
+    g.vt_perm = vt_perm ? 1 : 0;   // 1: the key order attention mode 3 reads
+    if (cfg < 0) HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
+    else if (launch_gemm_cfg(g, EPI_QKV, cfg, nullptr) != hipSuccess)
+        return set_err(VT_ERR_INVALID_ARG, "qkv: tile configuration %d does not fit this shape", cfg);
     HIPCHK(hipDeviceSynchronize());
     auto widen = [](const DevBuf& d, size_t count, float* out) -> hipError_t {
         std::vector<bf16_t> tmp(count);
@@ -1431,18 +1545,17 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     HIPCHK(widen(dqk, (size_t)M * 2 * D, qk_out));
     HIPCHK(widen(dvt, (size_t)B * H * 64 * npad, vt_out));
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v, float* out,
-                         int B, int N, int H) {
+                         int B, int N, int H, int mode) try {
     if (!q || !k || !v || !out || B <= 0 || N <= 0 || H <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(attention_prepare());
     const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
     // host-side packing into the layouts the QKV epilogue produces
-    const char* me = getenv("VT_ATTN_MODE");      // read per call: the tests switch modes
-    const int mode = me ? atoi(me) : attention_pick_mode(N, npad);
+    if (mode < 0) mode = attention_pick_mode(N, npad);
     const bool perm = attention_vt_perm(mode) != 0;
     std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad, 0);
     for (int m = 0; m < M; ++m) {
@@ -1462,14 +1575,14 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
     HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 // Timing helper: mean microseconds per launch of the attention kernel (mode as VT_ATTN_MODE, <0 =
 // the launcher's choice) on device-resident random data.
-int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out) {
+int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out) try {
     if (B <= 0 || N <= 0 || H <= 0 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     HIPCHK(attention_prepare());
     const int D = H * 64, M = B * N, npad = (N + 63) / 64 * 64;
     std::vector<bf16_t> qk((size_t)M * 2 * D), vt((size_t)B * H * 64 * npad);
@@ -1495,12 +1608,12 @@ int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iter
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *us_out = ms * 1000.0f / iters;
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
-int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta, float* y, int M, int D) {
+int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta, float* y, int M, int D) try {
     if (!x || !gamma || !beta || !y || M <= 0 || D % 128) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
-    HIPCHK(hipSetDevice(device_id));
+    DEVICE_SCOPE(device_id);
     DevBuf dx, dg, db, dy;
     HIPCHK(dx.alloc((size_t)M * D * 4)); HIPCHK(dg.alloc((size_t)D * 4)); HIPCHK(db.alloc((size_t)D * 4)); HIPCHK(dy.alloc((size_t)M * D * 2));
     HIPCHK(hipMemcpy(dx.p, x, (size_t)M * D * 4, hipMemcpyHostToDevice));
@@ -1512,6 +1625,6 @@ int vt_op_layernorm(int device_id, const float* x, const float* gamma, const flo
     HIPCHK(hipMemcpy(tmp.data(), dy.p, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(y + i, &u, 4); }
     return VT_OK;
-}
+} VT_NOTHROW_INT
 
 }  // extern "C"

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 1
+#define VT_ABI_VERSION 2   /* 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
 
 typedef enum vt_status {
     VT_OK = 0,
@@ -71,11 +71,16 @@ typedef struct vt_config {
     uint32_t struct_size;      /* = sizeof(vt_config); lets the struct grow */
     float success_threshold;   /* result.success = score >= this; <0 → blob default (0.20) */
     int32_t use_graph;         /* 1 (default): replay the frame as a hipGraph; 0: eager launches */
-    int32_t n_streams;         /* vt_group_create only: independent tracked streams on this GPU */
+    int32_t n_streams;         /* vt_group_create only: independent tracked streams on this GPU,
+                                * 1..VT_MAX_STREAMS */
     int32_t max_frame_width;   /* staging size for host-pointer calls; 0 → 3840 */
     int32_t max_frame_height;  /* 0 → 2160 */
-    int32_t reserved[8];
+    int32_t max_device_mib;    /* > 0: refuse (VT_ERR_OOM) to create an engine whose weights +
+                                * activations need more HBM than this; 0: only the device's free
+                                * memory limits it (checked before anything is allocated) */
+    int32_t reserved[7];
 } vt_config;
+#define VT_MAX_STREAMS 1024
 
 typedef struct vt_model_info {
     int32_t patch, template_size, search_size, dim, heads, layers, mlp_dim;
@@ -159,7 +164,13 @@ typedef struct vt_frame {        /* one device-resident frame (or a window of it
      * outside the stored window must not be needed by the call (the tracker reads the search
      * window, side 4*sqrt(w*h) around the last box, plus one pixel). 0,0 = the whole frame. */
     int32_t origin_x, origin_y;
-    int32_t reserved;            /* 1: strides describe a window narrower than the frame */
+    int32_t windowed;            /* 1: the planes hold only window_w x window_h pixels (strides
+                                  * describe that window); 0 with origin 0,0: the whole frame */
+    /* Extent of the stored window in pixels (required when windowed == 1 or an origin is set; both
+     * even for NV12, window_w even for YUY2, unless the window ends at the frame's edge). A sample
+     * that falls inside the frame but outside the stored window reads as black - never out of
+     * bounds. 0,0 with no origin: width x height. */
+    int32_t window_w, window_h;
 } vt_frame;
 
 int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out);
@@ -270,8 +281,9 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
 /* Stage taps: when enabled the pass runs eagerly and keeps a copy of the residual stream after the
  * patch embedding and after every encoder block (for stage-level parity tests). */
 int vt_group_enable_taps(vt_group* g, int enable);
-/* A single tracker viewed as a group of one (taps, profiling, stream handle). The view is
- * thread-local and valid until the next call of this function on the same thread. */
+/* A single tracker viewed as a group of one (taps, profiling, stream handle). The view belongs to
+ * the tracker: valid until vt_destroy(t), the same pointer on every call, never to be destroyed
+ * by the caller. */
 vt_group* vt_tracker_as_group(vt_tracker* t);
 
 /* Overwrite the box the next update of `stream` crops its search window around (x, y, w, h in frame
@@ -292,26 +304,29 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
 
 /* C[M,N] (f32) = A[M,K] (bf16 bits) x W[N,K]^T (bf16 bits) + bias[N]; epilogue:
  * 0 = f32 store, 1 = C += (residual), 2 = GELU -> bf16 (returned widened to f32),
- * 3 = ReLU -> bf16 (widened). Host pointers. K % 64 == 0, N % 64 == 0. */
+ * 3 = ReLU -> bf16 (widened). Host pointers. K % 64 == 0, N % 64 == 0. cfg: tile configuration as
+ * in vt_op_gemm_bench (< 0: the launcher's own choice for the shape). */
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                    float* c_inout, int M, int N, int K, int epilogue);
+                    float* c_inout, int M, int N, int K, int epilogue, int cfg);
 /* Kernel-tuning helper: mean microseconds per launch of the GEMM kernel on device-resident random
  * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
  * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2,
- * <0 = the launcher's own choice. */
+ * 17 = 256x256 8-wave, <0 = the launcher's own choice. */
 int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
                      float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
- * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. */
+ * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;
+ * vt_perm = 1: Vt in the key order attention mode 3 reads (attn_perm16 inside every 16 keys). */
 int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                   float* qk_out, float* vt_out, int B, int tokens, int D);
+                   float* qk_out, float* vt_out, int B, int tokens, int D, int cfg, int vt_perm);
 /* out[B,N,H*64] (bf16 widened to f32) = softmax(q k^T) v per head; q,k,v: [B,N,H*64] bf16 bits
- * (q already scaled). */
+ * (q already scaled). mode as in vt_op_attention_bench. */
 int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v,
-                         float* out, int B, int N, int H);
+                         float* out, int B, int N, int H, int mode);
 /* Kernel-tuning helper: mean microseconds per launch of the attention kernel on random data;
- * mode 0 key-split, 1 independent waves, 2 LDS-shared tiles, <0 the launcher's choice. */
+ * mode 0 key-split, 1 independent waves, 2 LDS-shared tiles, 3 LDS-DMA ring (permuted Vt),
+ * <0 the launcher's choice. */
 int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out);
 /* y[M,D] (bf16 widened) = LayerNorm(x[M,D] f32; gamma, beta, eps=1e-6) */
 int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta,

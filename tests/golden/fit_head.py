@@ -99,7 +99,7 @@ class Head(torch.nn.Module):
         return self.c4(x).permute(0, 3, 1, 2)  # [n, 5, g, g]
 
 
-def fit(cfg_name: str, n_train: int, steps: int):
+def fit(cfg_name: str, n_train: int, steps: int, out_path: str | None = None):
     cfg = vt.weights.get_config(cfg_name)
     torch.manual_seed(0)
     t0 = time.time()
@@ -169,11 +169,13 @@ def fit(cfg_name: str, n_train: int, steps: int):
     # the bf16 tensors are stored as the bf16-rounded values so the asset is what the blob holds
     for k in vt.weights.HEAD_BF16:
         asset[k] = R.bf16r(asset[k].astype(np.float32))
-    path = vt.weights.head_asset_path(cfg)
+    path = out_path or vt.weights.head_asset_path(cfg)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.savez_compressed(path, **{k: v.astype(np.float32) for k, v in asset.items()})
     print(f"[{cfg.name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
-    validate(cfg_name)
+    if out_path is None:
+        validate(cfg_name)
+    return asset
 
 
 def make_samples_gpu(cfg, n: int, seed: int, w=960, h=540, bs=32):

@@ -21,7 +21,7 @@ def test_hip_library_exports_every_declared_symbol(vt):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(vt.EXPORTS) == names
-    assert L.vt_abi_version() == 1
+    assert L.vt_abi_version() == 2
 
 
 def test_host_library_exports_every_declared_symbol(vt):
@@ -36,7 +36,7 @@ def test_host_library_exports_every_declared_symbol(vt):
 def test_struct_layouts_match_header(vt):
     assert ctypes.sizeof(vt.CBBox) == 16
     assert ctypes.sizeof(vt.CResult) == 24       # 24 B of result per frame
-    assert ctypes.sizeof(vt.CFrame) == 48
+    assert ctypes.sizeof(vt.CFrame) == 56       # ABI 2: + window_w, window_h
     assert ctypes.sizeof(vt.CConfig) == 24 + 32
     assert ctypes.sizeof(vt.CKernelTime) == 48 + 8 + 16
 

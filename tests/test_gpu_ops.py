@@ -34,12 +34,11 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
+def test_gemm_every_tile_config(gpu, cfg, epi):
     """each tile configuration (64x64 / 128x128 with ring 2..4, and the 256x256 8-wave kernel) on a
     ragged M, against float32 NumPy"""
-    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
     rng = np.random.default_rng(cfg * 10 + epi)
     M, N, K = 720 + 37, 768, 384
     ab, a = _rand_bf16(gpu, rng, (M, K))
@@ -47,7 +46,7 @@ def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
     bias = rng.standard_normal(N).astype(np.float32)
     c0 = rng.standard_normal((M, N)).astype(np.float32)
     z = a @ w.T + bias
-    got = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=epi)
+    got = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=epi, cfg=cfg)
     if epi == 0:
         assert np.abs(got - z).max() < 2e-3
     elif epi == 1:
@@ -57,16 +56,15 @@ def test_gemm_every_tile_config(gpu, monkeypatch, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17])
-def test_qkv_every_tile_config(gpu, monkeypatch, cfg):
-    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18])
+def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)
     B, tokens, D = 2, 100, 768
     ab, a = _rand_bf16(gpu, rng, (B * tokens, D))
     wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
     bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
     z = a @ w.T + bias
-    qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
+    qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D, cfg=cfg)
     ref_qk = np.concatenate([z[:, :D] * QK_SCALE, z[:, D:2 * D]], axis=1)
     assert np.all(np.abs(qk - ref_qk) <= np.abs(ref_qk) * 2 ** -8 + 1e-3)
     v = z[:, 2 * D:].reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
@@ -86,31 +84,32 @@ def test_gemm_exact_integers_asymmetric(gpu):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (256, 512, 256), (1000, 768, 1024)])
-def test_gemm256_exact_integers(gpu, monkeypatch, M, N, K):
-    """the 256x256 8-wave kernel (config 17) on small-integer operands: every product and sum is
-    exact, so any mis-staged half-tile, swizzle slip or early read of a buffer shows as a wrong
-    integer; K = 128 is the shortest supported loop (prologue + the two tail tiles only)"""
-    monkeypatch.setenv("VT_GEMM_CFG", "17")
+@pytest.mark.parametrize("cfg", [17, 18])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (256, 512, 256), (1000, 768, 1024), (513, 256, 192)])
+def test_gemm256_exact_integers(gpu, M, N, K, cfg):
+    """the 256x256 8-wave kernels (config 17: 4 phases per K-tile, 18: 2 long phases) on small-integer
+    operands: every product and sum is exact, so any mis-staged half-tile, swizzle slip or early
+    read of a buffer shows as a wrong integer; K = 128 is the shortest supported loop (prologue +
+    the two tail tiles only), K = 192 runs the steady-state body exactly once"""
     rng = np.random.default_rng(M + N + K)
     a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
     w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
     bias = rng.integers(-8, 9, size=N).astype(np.float32)
     c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
     ref = a @ w.T + bias
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0), ref)
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1),
-                          ref + c0)
-    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0, cfg=cfg), ref)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1,
+                                           cfg=cfg), ref + c0)
+    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3, cfg=cfg)
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
-def test_gemm256_full_chip_exact_integers(gpu, monkeypatch):
+@pytest.mark.parametrize("cfg", [17, 18])
+def test_gemm256_full_chip_exact_integers(gpu, cfg):
     """config 17 at the bench's size (30 streams: M = 21,600, fc1 shape, 1020 workgroups = 4 rounds
     on 256 CUs) with small-integer operands: every output must be the exact integer, three launches
     in a row. A half-tile read before its LDS-DMA landed, or overwritten while still being read,
     only shows under full-chip memory load - this is the case the small shapes cannot reach."""
-    monkeypatch.setenv("VT_GEMM_CFG", "17")
     rng = np.random.default_rng(2026)
     M, N, K = 21600, 3072, 768
     a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
@@ -119,25 +118,28 @@ def test_gemm256_full_chip_exact_integers(gpu, monkeypatch):
     ref = a @ w.T + bias          # |sums| <= 12,296: exact in float32 in any order
     ab, wb = _bits(gpu, a), _bits(gpu, w)
     for _ in range(3):
-        got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0)
+        got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg)
         assert np.array_equal(got, ref)
+    c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=1, cfg=cfg), ref + c0)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=cfg), bf16_round(np.maximum(ref, 0)))
 
 
-def test_gemm256_long_k_repeatable(gpu, monkeypatch):
+@pytest.mark.parametrize("cfg", [17, 18])
+def test_gemm256_long_k_repeatable(gpu, cfg):
     """config 17 on the fc2 shape of 4 streams (48 K-tiles, 36 workgroups), five launches: the
     results must agree with float32 NumPy and be bit-identical from launch to launch (a race
     between the LDS-DMA ring and the fragment reads would show as run-to-run differences)"""
-    monkeypatch.setenv("VT_GEMM_CFG", "17")
     rng = np.random.default_rng(17)
     M, N, K = 2880, 768, 3072
     ab, a = _rand_bf16(gpu, rng, (M, K))
     wb, w = _rand_bf16(gpu, rng, (N, K), 0.02)
     bias = rng.standard_normal(N).astype(np.float32)
     ref = a @ w.T + bias
-    first = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0)
+    first = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg)
     assert np.abs(first - ref).max() < 2e-3
     for _ in range(4):
-        assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=0), first)
+        assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg), first)
 
 
 def test_gemm_residual(gpu):
@@ -202,16 +204,15 @@ def _attn_ref(q, k, v, B, N, H):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0),
                                          (1, 980, 16, 0.5), (1, 33, 1, 3.0), (3, 100, 2, 1.0)])
-def test_attention(gpu, monkeypatch, B, N, H, scale, mode):
+def test_attention(gpu, B, N, H, scale, mode):
     """mode 0: key-split waves, 1: independent waves, 2: K/Vt tiles shared through LDS"""
-    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     rng = np.random.default_rng(N + H)
     D = H * 64
     qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
     kb, k = _rand_bf16(gpu, rng, (B * N, D), scale)
     vb, v = _rand_bf16(gpu, rng, (B * N, D))
     ref = _attn_ref(q, k, v, B, N, H)
-    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode)
     err = np.abs(got - ref)
     # P is rounded to bf16 before the PV product and the output is bf16
     assert err.max() < 0.02 * max(1.0, np.abs(ref).max()), err.max()
@@ -221,30 +222,29 @@ def test_attention(gpu, monkeypatch, B, N, H, scale, mode):
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
                                          (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
                                          (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
-def test_attention_mode3(gpu, monkeypatch, B, N, H, scale):
+def test_attention_mode3(gpu, B, N, H, scale):
     """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
     Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
     (320), more tiles than ring stages (1008), token counts that are not multiples of 16 (100, 980,
     36: the last 16-key group is partly padding) and a ragged last query block."""
-    monkeypatch.setenv("VT_ATTN_MODE", "3")
+    mode = 3
     rng = np.random.default_rng(N + H)
     D = H * 64
     qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
     kb, k = _rand_bf16(gpu, rng, (B * N, D), scale)
     vb, v = _rand_bf16(gpu, rng, (B * N, D))
     ref = _attn_ref(q, k, v, B, N, H)
-    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode)
     err = np.abs(got - ref)
     assert err.max() < 0.02 * max(1.0, np.abs(ref).max()), err.max()
     assert err.mean() < 2e-3
-    assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H))   # run-to-run identical
+    assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3])
-def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
+def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
     sequence: the reference must move and everything accumulated before be rescaled"""
-    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     rng = np.random.default_rng(77)
     B, N, H = 1, 320, 2
     D = H * 64
@@ -255,7 +255,7 @@ def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
     k = gpu.weights.bf16_bits_to_f32(kb)
     vb, v = _rand_bf16(gpu, rng, (N, D))
     ref = _attn_ref(q, k, v, B, N, H)
-    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode)
     err = np.abs(got - ref)
     assert np.isfinite(got).all()
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
@@ -263,11 +263,10 @@ def test_attention_late_maximum_rescale(gpu, monkeypatch, mode):
 
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("level", [-20.0, -64.0, -150.0, 90.0])
-def test_attention_uniformly_offset_scores(gpu, monkeypatch, mode, level):
+def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
     p = 2^s as is (-20), below it the first step must adopt the maximum or the row would underflow
     (-64, -150), above it the reference must move before 2^s overflows (+90)"""
-    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
     rng = np.random.default_rng(int(abs(level)))
     B, N, H = 1, 192, 1
     q = np.zeros((N, 64), np.float32)
@@ -280,26 +279,24 @@ def test_attention_uniformly_offset_scores(gpu, monkeypatch, mode, level):
     qb, kb = _bits(gpu, q), _bits(gpu, k)
     q, k = gpu.weights.bf16_bits_to_f32(qb), gpu.weights.bf16_bits_to_f32(kb)
     ref = _attn_ref(q, k, v, B, N, H)
-    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H)
+    got = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < 0.02 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 17])
+@pytest.mark.parametrize("cfg", [2, 3, 17, 18])
 @pytest.mark.parametrize("tokens", [112, 100])
-def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg, tokens):
+def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     """Vt as attention mode 3 reads it: inside every group of 16 tokens OF A STREAM the 4-token runs
     1 and 2 swap places (position = token with bits 2 and 3 exchanged). 112: streams start on
     16-token boundaries (whole 16-B pieces); 100: they do not (run-by-run placement)"""
-    monkeypatch.setenv("VT_GEMM_CFG", str(cfg))
-    monkeypatch.setenv("VT_QKV_PERM", "1")
     rng = np.random.default_rng(cfg)
     B, D = 3, 768
     ab, a = _rand_bf16(gpu, rng, (B * tokens, D))
     wb, w = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
     bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
     z = a @ w.T + bias
-    _, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D)
+    _, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D, cfg=cfg, vt_perm=1)
     v = z[:, 2 * D:].reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
     t = np.arange(tokens)
     pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
@@ -310,8 +307,7 @@ def test_qkv_permuted_vt_layout(gpu, monkeypatch, cfg, tokens):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_attention_exact_selector(gpu, monkeypatch, mode):
-    monkeypatch.setenv("VT_ATTN_MODE", str(mode))
+def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
     N, H = 96, 1
@@ -326,7 +322,7 @@ def test_attention_exact_selector(gpu, monkeypatch, mode):
         q[i, j % 32] = 4.0
         q[i, 32 + j // 32] = 4.0
     v = ((np.arange(N)[:, None] * 5 + np.arange(64)[None, :] * 3) % 31 - 15).astype(np.float32)
-    got = gpu.op_attention_bf16(_bits(gpu, q), _bits(gpu, k), _bits(gpu, v), 1, N, H)
+    got = gpu.op_attention_bf16(_bits(gpu, q), _bits(gpu, k), _bits(gpu, v), 1, N, H, mode=mode)
     assert np.abs(got - v[sel]).max() < 1e-3
 
 

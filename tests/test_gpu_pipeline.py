@@ -287,7 +287,7 @@ def test_group_host_frames_equal_device_frames(gpu, weights_tiny):
                 dframes.append(gpu.frame_nv12(d.data_ptr(), d.data_ptr() + w * h, w, h))
             elif isinstance(f, gpu.YUY2Frame):
                 d = torch.from_numpy(f.buf).cuda()
-                dframes.append(gpu.CFrame(d.data_ptr(), None, w, h, 2 * w, 0, gpu.PIX_YUY2, 0, 0, 0))
+                dframes.append(gpu.CFrame(d.data_ptr(), None, w, h, 2 * w, 0, gpu.PIX_YUY2, 0, 0, 0, 0, 0))
             else:
                 d = torch.from_numpy(np.ascontiguousarray(f)).cuda()
                 dframes.append(gpu.frame_rgb8(d.data_ptr(), w, h))
