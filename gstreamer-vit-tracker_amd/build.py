@@ -32,6 +32,10 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
 # fused multiply-add allowed where no bit-exact float spec applies (MFMA kernels' epilogues and
 # softmax); the pixel stage and the box decode keep one IEEE operation per source operation
 FAST_CONTRACT = {"k_gemm.hip", "k_gemm256.hip", "k_attn.hip"}
+# k_gemm256.hip: hipcc's SLP vectoriser packs the last FMA of the GELU epilogue into v_pk_fma_f32,
+# which has no |x| modifier, so it also emits one v_or per element to build -|x| (and a packed f32
+# op issues at the rate of two scalar ones on CDNA4): 8 % more epilogue VALU for nothing
+EXTRA_FLAGS = {"k_gemm256.hip": ["-fno-slp-vectorize"]}
 HOST_SOURCES = ["host_capi.cpp"]
 
 
@@ -51,7 +55,14 @@ def _run(cmd: list[str]) -> None:
         sys.stderr.write(r.stderr)
 
 
-def build_hip(force: bool = False, save_temps: bool = False) -> str:
+def build_hip(force: bool = False, save_temps: bool = False, stamps: bool = False) -> str:
+    """stamps=True: the diagnostic build (-DVT_STAMPS: in-kernel cycle stamps in the GEMM main loops,
+    printed by vt_op_gemm_bench) into libvittrack_hip_stamps.so; never loaded by the product - point
+    VITTRACK_HIP_LIB at it from a tuning tool."""
+    global OBJ, LIB_HIP
+    if stamps:
+        OBJ = os.path.join(PKG, "build_stamps")
+        LIB_HIP = os.path.join(PKG, "libvittrack_hip_stamps.so")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "vt_common.hpp"), os.path.join(CSRC, "k_gemm_util.hpp"),
                os.path.join(PKG, "..", "include", "vittrack_hip.h")]
@@ -61,10 +72,10 @@ def build_hip(force: bool = False, save_temps: bool = False) -> str:
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            flags = list(HIP_FLAGS)
+            flags = list(HIP_FLAGS) + (["-DVT_STAMPS"] if stamps else [])
             if s in FAST_CONTRACT:
                 flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
-            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -93,6 +104,9 @@ def build_all(force: bool = False):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
+    if "--stamps" in sys.argv:
+        print(build_hip(force, stamps=True))
+        sys.exit(0)
     print(build_hip(force, save_temps="--save-temps" in sys.argv))
     if os.path.exists(os.path.join(HOST, "host_capi.cpp")):
         print(build_host(force))

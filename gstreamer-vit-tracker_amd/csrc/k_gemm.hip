@@ -398,7 +398,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(1, 128, 128, 2, 2, 3, EPI)  \
     X(2, 64, 64, 2, 2, 2, EPI)    \
     X(3, 128, 128, 2, 2, 2, EPI)
-#define GEMM_NUM_CFG 19   // valid: 0..3 (this file) and 17, 18 (k_gemm256.hip)
+#define GEMM_NUM_CFG 20   // valid: 0..3 (this file) and 17, 18, 19 (k_gemm256.hip)
 
 template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
 static hipError_t prepare_cfg() {
@@ -451,7 +451,9 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
     // about half a round upwards unless the last round is nearly empty (profiles/gemm_sweep_r01.txt)
     if ((N % 256) == 0 && K >= 128) {
         const long t = (long)((M + 255) / 256) * (N / 256), rounds = (t + 255) / 256;
-        if (t >= 128 && (rounds == 1 || t * 10 >= rounds * 256 * 6)) return GEMM_CFG_256P8;
+        // 19 = schedule v2 with persistent workgroups where that applies (bf16 outputs, more tiles
+        // than CUs), else the one-tile-per-workgroup launch of the same schedule (= 18)
+        if (t >= 128 && (rounds == 1 || t * 10 >= rounds * 256 * 6)) return GEMM_CFG_256PP;
     }
     switch (epilogue) {
         case EPI_QKV:
@@ -469,6 +471,7 @@ const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
     if (cfg == GEMM_CFG_256P8) return "256x256p8";
     if (cfg == GEMM_CFG_256P4) return "256x256p4";
+    if (cfg == GEMM_CFG_256PP) return "256x256pp";
     return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
 }
 
@@ -489,6 +492,7 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
         return hipErrorInvalidValue;
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
     if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
+    if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);
     switch (epilogue) {
         case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
         case EPI_RESID: return launch_epi<EPI_RESID>(a, cfg, st);

@@ -66,6 +66,28 @@ __device__ __forceinline__ f32x4_t mma16(const bf16x8_t& xa, const bf16x8_t& wb,
 
 #define G256_RD(ptr, off) (*reinterpret_cast<const bf16x8_t*>((ptr) + (off)))
 
+// LDS accesses of the persistent kernel's wave-private epilogue, as inline asm: hipcc (ROCm 7.2) puts
+// an s_waitcnt vmcnt(0) in front of compiler-visible LDS reads that follow the epilogue's LDS-DMA
+// prologue pieces and global stores, which drains both in every block. Operations without a VGPR
+// destination are register-safe; the reads are form (ii) of the guide (s5.7): "=v" destinations, and
+// one wait statement naming every destination "+v" before the first consumer.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write64_asm(uint32_t addr, uint32_t lo, uint32_t hi) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <int OFF>
+__device__ __forceinline__ void lds_read128_asm(u32x4_t& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wait2_asm(u32x4_t& a, u32x4_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
+
 #define G256_READ_A(I)                                                        \
     _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                        \
         Af[mf][0] = G256_RD(pa0, (I) * G256_HALF + mf * 2048);                \
@@ -607,6 +629,383 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+// ---- persistent variant (config 19): bf16-output GEMMs that need several rounds of the chip ----------
+// Measured on fc1 (M = 21,600, N = 3072, K = 768; 1020 tiles = 4 rounds of 256 workgroups): a round
+// costs 29 us of which the main loop is 16-17; the rest is per-tile overhead that nothing overlaps
+// when a fresh workgroup owns the CU for exactly one tile: ~3 us until the LDS-DMA pipeline is full,
+// ~3.6 us of bias/activation/pack + LDS transpose, ~3.7 us of stores that all 256 CUs issue in the same
+// microsecond (33 MB burst). Here 256 workgroups stay resident and walk the tiles:
+//   * the 12 LDS-DMA pieces of the NEXT tile's prologue are issued right after the last barrier of a
+//     tile's main loop, BEFORE its epilogue: the pipeline fill runs under the epilogue;
+//   * the epilogue is wave-private: each wave transposes its own 128 x 64 piece through its own 4 KiB
+//     of the 32 KiB of LDS the operand ring leaves free (four passes of 32 rows x 128 B, no workgroup
+//     barrier), so the ring can be refilled meanwhile and fast waves are not held back;
+//   * the CUs drift apart after the first tile, so the stores no longer hit HBM as one burst;
+//   * tiles are dealt so that the 32 workgroups sharing an XCD (blockIdx % 8, placement is a speed
+//     assumption only) run a compact block of ~(32 / cgw) x cgw tiles per round: fewer distinct A/W
+//     panels per XCD than 32 consecutive row-major tiles (11.3 instead of 14.7 for N = 3072).
+// QKV column tiles that hold V (transposed scatter) keep the block-wide epilogue through the ring and
+// issue the next prologue after it.
+#define G256P_STAGE (2 * G256_BUF)            // byte offset of the wave-private staging area
+#define G256P_LDS (2 * G256_BUF + 8 * 4096)   // 160 KiB: all of a CU's LDS
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, int cgw) {
+    static_assert(EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_QKV, "bf16 outputs only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q = lane >> 4;
+    const int tiles_m = (p.M + 255) >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_round = (gridDim.x >> 3);
+    // tile `seq` of the column-group-major order: groups of cgw column tiles, rows inside a group
+    const int per_group = tiles_m * cgw;
+#define G256P_TILE(SEQ, M0, N0)                                      \
+    {                                                                \
+        const int g_ = (SEQ) / per_group, r_ = (SEQ) % per_group;    \
+        M0 = (r_ / cgw) << 8;                                        \
+        N0 = (g_ * cgw + r_ % cgw) << 8;                             \
+    }
+    // staging pieces and fragment addresses as in g256_mainloop2
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    uint32_t aoff00, aoff01, aoff10, aoff11, boff00, boff01, boff10, boff11;
+#define G256P_OFFSETS(M0, N0)                                                                    \
+    {                                                                                            \
+        int r0_ = (M0) + srow, r1_ = (M0) + 128 + srow, r2_ = (M0) + 64 + srow, r3_ = (M0) + 192 + srow; \
+        r0_ = r0_ < p.M ? r0_ : p.M - 1; r1_ = r1_ < p.M ? r1_ : p.M - 1;                        \
+        r2_ = r2_ < p.M ? r2_ : p.M - 1; r3_ = r3_ < p.M ? r3_ : p.M - 1;                        \
+        aoff00 = (uint32_t)((r0_ * p.lda + schunk * 8) * 2);                                     \
+        aoff01 = (uint32_t)((r1_ * p.lda + schunk * 8) * 2);                                     \
+        aoff10 = (uint32_t)((r2_ * p.lda + schunk * 8) * 2);                                     \
+        aoff11 = (uint32_t)((r3_ * p.lda + schunk * 8) * 2);                                     \
+        const int bn_ = (N0) + (srow >> 5) * 64 + (srow & 31);                                   \
+        boff00 = (uint32_t)(((bn_) * p.ldw + schunk * 8) * 2);                                   \
+        boff01 = (uint32_t)(((bn_ + 128) * p.ldw + schunk * 8) * 2);                             \
+        boff10 = (uint32_t)(((bn_ + 32) * p.ldw + schunk * 8) * 2);                              \
+        boff11 = (uint32_t)(((bn_ + 160) * p.ldw + schunk * 8) * 2);                             \
+    }
+#define G256P_PROLOGUE()                   \
+    G256_STAGE_B(0, 0, 0)                  \
+    G256_STAGE_B(1, 0, 0)                  \
+    G256_STAGE_A(0, 0, 0)                  \
+    G256_STAGE_A(1, 0, 0)                  \
+    G256_STAGE_B(0, 1, G256_BUF)           \
+    G256_STAGE_B(1, 1, G256_BUF)
+    const int sw = (lane >> 1) & 7;
+    const uint32_t a_k0 = (uint32_t)((wr * 64 + l15) * 128 + ((q ^ sw) << 4));
+    const uint32_t b_k0 = (uint32_t)(2 * G256_HALF + (wc * 32 + l15) * 128 + ((q ^ sw) << 4));
+    const int nk = p.K >> 6;
+
+    int seq = xcd * 32 + slot;                 // round 0: chunk xcd
+    const int seq_step = 8 * 32;               // next round: chunk + 8
+    (void)per_round;
+    int m0 = 0, n0 = 0;
+    bool after16 = false;
+#ifdef VT_STAMPS
+    unsigned long long sp_wait = 0, sp_main = 0, sp_epi = 0, sp_a, sp_b;
+    const unsigned long long sp_t0 = __builtin_amdgcn_s_memtime();
+#define G256P_T(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define G256P_T(v)
+#endif
+    if (slot < 32 && seq < tiles) {
+        G256P_TILE(seq, m0, n0)
+        G256P_OFFSETS(m0, n0)
+        G256P_PROLOGUE()
+    }
+    for (; slot < 32 && seq < tiles; seq += seq_step) {
+        acc256_t acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) acc[i][mf][j][nf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        bool v_tile = false;
+        float scale = 1.0f;
+        if constexpr (EPI == EPI_QKV) {
+            v_tile = n0 >= 2 * p.D;
+            scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;
+        }
+        // ---- main loop (schedule v2); its prologue was issued before the previous tile's epilogue.
+        // The counted waits below assume only LDS-DMA in the queue; stores of the previous epilogue
+        // that are still in flight sit between the prologue pieces and this tile's first staging
+        // pieces, so the first waits may also wait for them (over-waiting is always safe).
+        {
+            const char* pa0 = smem + a_k0;
+            const char* pa1 = smem + (a_k0 ^ 64);
+            const char* pb0 = smem + b_k0;
+            const char* pb1 = smem + (b_k0 ^ 64);
+            bf16x8_t Af[4][2], Bf[2][2][2];
+            // `after16`: the previous epilogue of this wave interleaved its 16 stores with the 12
+            // prologue pieces in the order shown there (vmcnt retires loads, stores and LDS-DMA
+            // together, in issue order). B(0), A0(0) = the first 6 pieces have 18 younger operations
+            // behind them; after the 4 pieces of A(1) are issued, A1(0) has 18 as well: the first two
+            // waits of this tile leave the stores in flight instead of waiting for their acknowledgement
+            bool first_kt = after16;
+            G256P_T(sp_a)
+            if (first_kt) wait_vmcnt<18>(); else wait_vmcnt<6>();
+            __builtin_amdgcn_s_barrier();
+            if (wr == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef VT_STAMPS
+            G256P_T(sp_b) sp_wait += sp_b - sp_a;
+#endif
+            int bo = 0, kt = 0;
+#define G256_FLIP()                                                           \
+    bo ^= G256_BUF;                                                           \
+    pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);                \
+    pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
+#define G256P_BODY(SW)                                                        \
+            for (; kt < nk - 2; ++kt) {                                       \
+                const int bn = bo ^ G256_BUF;                                 \
+                G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)                  \
+                G256_STAGE_A(0, kt + 1, bn)                                   \
+                G256_STAGE_A(1, kt + 1, bn)                                   \
+                if (first_kt) wait_vmcnt<18>(); else wait_vmcnt<8>();         \
+                first_kt = false;                                             \
+                G256_COMPUTE2(0)                                              \
+                G256_READ_A(1)                                                \
+                G256_STAGE_B(0, kt + 2, bo)                                   \
+                G256_STAGE_B(1, kt + 2, bo)                                   \
+                wait_vmcnt<6>();                                              \
+                G256_COMPUTE2(1)                                              \
+                G256_FLIP()                                                   \
+            }                                                                 \
+            {                                                                 \
+                const int bn = bo ^ G256_BUF;                                 \
+                G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)                  \
+                G256_STAGE_A(0, kt + 1, bn)                                   \
+                G256_STAGE_A(1, kt + 1, bn)                                   \
+                if (first_kt) wait_vmcnt<18>(); else wait_vmcnt<8>();         \
+                first_kt = false;                                             \
+                G256_COMPUTE2(0)                                              \
+                G256_READ_A(1)                                                \
+                wait_vmcnt<2>();                                              \
+                G256_COMPUTE2(1)                                              \
+                G256_FLIP()                                                   \
+            }                                                                 \
+            {                                                                 \
+                G256_READ_B(0) G256_READ_B(1) G256_READ_A(0)                  \
+                wait_vmcnt<0>();                                              \
+                G256_COMPUTE2(0)                                              \
+                G256_READ_A(1)                                                \
+                G256_COMPUTE2(1)                                              \
+            }
+            if (!v_tile) {
+                constexpr bool SWAP = true;
+                G256P_BODY(true)
+            } else {
+                constexpr bool SWAP = false;
+                G256P_BODY(false)
+            }
+#undef G256_FLIP
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef VT_STAMPS
+            G256P_T(sp_a) sp_main += sp_a - sp_b;
+#endif
+        }
+        // every wave has finished reading the ring
+        const int tm0 = m0, tn0 = n0;                 // the tile whose accumulators we hold
+        const int nseq = seq + seq_step;
+        const bool more = nseq < tiles;
+        after16 = false;
+        if (more) { G256P_TILE(nseq, m0, n0) }
+        if (!v_tile) {
+            if (more) { G256P_OFFSETS(m0, n0) }
+            // ---- wave-private epilogue, software-pipelined over the wave's eight 16-row blocks
+            // (block k = accumulator rows i = k >> 2, mf = k & 3; two 2-KiB halves of this wave's
+            // 4 KiB of staging LDS alternate):
+            //     bias / activation / pack block k -> ds_write (half k & 1)
+            //     global stores of block k-1 (its LDS reads were issued one block ago)
+            //     one sixth of the NEXT tile's prologue (2 LDS-DMA pieces; the ring is dead)
+            //     ds_read block k
+            // so the LDS round trip, the store issue and the LDS-DMA issue back-pressure (each ~100+
+            // cycles when issued back to back) sit between VALU work instead of stalling the wave.
+            // LDS executes one wave's operations in order: no wait is needed between a wave's own
+            // write and read of a half, nor before it overwrites a half it has already read.
+            // Lane-derived addresses are rebuilt from an opaque copy of the thread id: hoisted out of
+            // the tile loop they would be spilled around the main loop (guide: "a lane-constant address
+            // hoisted to kernel entry is spilled around the tile loop - recompute per block").
+            int te = tid;
+            asm volatile("" : "+v"(te));
+            const int el = te & 63, e15 = el & 15, eq = el >> 4;
+            f32x4_t bias4[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    bias4[j][nf] = *reinterpret_cast<const f32x4_t*>(
+                        p.bias + tn0 + wc * 64 + j * 32 + nf * 16 + 4 * eq);
+            char* ow = smem + G256P_STAGE + wave * 4096;
+            const int rr = el >> 3, rc = el & 7;       // read-out: 8 rows per instruction, 16-B chunk rc
+            bf16_t* const obase = (EPI == EPI_QKV)
+                                      ? p.qk + (size_t)(tm0 + wr * 128 + rr) * (2 * p.D) + tn0 + wc * 64 + rc * 8
+                                      : p.Cb + (size_t)(tm0 + wr * 128 + rr) * p.ldcb + tn0 + wc * 64 + rc * 8;
+            const size_t ostride8 = 8 * ((EPI == EPI_QKV) ? (size_t)(2 * p.D) : (size_t)p.ldcb);
+            const int rows_left = p.M - (tm0 + wr * 128);   // rows of this wave's piece inside M (wave-uniform)
+            const bool full = rows_left >= 128;
+            const int wsw = (e15 & 7) << 1;
+            const uint32_t wb_ = lds_addr(ow) + e15 * 128;
+            // 8-B piece c8 = j*8 + nf*4 + eq of row e15, stored at c8 ^ wsw
+            const uint32_t wa00 = wb_ + (((0 + eq) ^ wsw) << 3), wa01 = wb_ + (((4 + eq) ^ wsw) << 3);
+            const uint32_t wa10 = wb_ + (((8 + eq) ^ wsw) << 3), wa11 = wb_ + (((12 + eq) ^ wsw) << 3);
+            const uint32_t ra = lds_addr(ow) + rr * 128 + ((rc ^ rr) << 4);
+            u32x4_t o0, o1;
+#define G256P_STORE(KB)                                                                           \
+    lds_wait2_asm(o0, o1);                                                                       \
+    if (full) {                                                                                  \
+        *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0;                 \
+        *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1;             \
+    } else {                                                                                     \
+        if ((KB) * 16 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0; \
+        if ((KB) * 16 + 8 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1; \
+    }
+#define G256P_EPI_ONE(K, J, NF, WA)                                                              \
+    {                                                                                            \
+        float v[4];                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+            const float x = acc[(K) >> 2][(K) & 3][J][NF][e] + bias4[J][NF][e];                  \
+            if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);                              \
+            else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);                      \
+            else v[e] = x * scale;                                                               \
+        }                                                                                        \
+        lds_write64_asm<((K) & 1) * 2048>(WA, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); \
+    }
+#define G256P_EPI_BLOCK(K, STAGE_STMT)                                                           \
+    {                                                                                            \
+        G256P_EPI_ONE(K, 0, 0, wa00)                                                             \
+        G256P_EPI_ONE(K, 0, 1, wa01)                                                             \
+        G256P_EPI_ONE(K, 1, 0, wa10)                                                             \
+        G256P_EPI_ONE(K, 1, 1, wa11)                                                             \
+        if ((K) > 0) { G256P_STORE((K) - 1) }                                                    \
+        if (more) { STAGE_STMT }                                                                 \
+        lds_read128_asm<((K) & 1) * 2048>(o0, ra);                                               \
+        lds_read128_asm<((K) & 1) * 2048 + 1024>(o1, ra);                                        \
+    }
+            G256P_EPI_BLOCK(0, G256_STAGE_B(0, 0, 0))
+            G256P_EPI_BLOCK(1, G256_STAGE_B(1, 0, 0))
+            G256P_EPI_BLOCK(2, G256_STAGE_A(0, 0, 0))
+            G256P_EPI_BLOCK(3, G256_STAGE_A(1, 0, 0))
+            G256P_EPI_BLOCK(4, G256_STAGE_B(0, 1, G256_BUF))
+            G256P_EPI_BLOCK(5, G256_STAGE_B(1, 1, G256_BUF))
+            G256P_EPI_BLOCK(6, )
+            G256P_EPI_BLOCK(7, )
+            G256P_STORE(7)
+#undef G256P_EPI_BLOCK
+#undef G256P_EPI_ONE
+#undef G256P_STORE
+            // queue of this wave now: g g | s s g g | s s g g | s s g g | s s g g | s s g g | s s | s s | s s
+            after16 = more && full;
+        } else if constexpr (EPI == EPI_QKV) {
+            // V tile: block-wide transpose through the (dead) ring, then the next prologue
+            const int heads = p.D >> 6;
+            int tv = tid;
+            asm volatile("" : "+v"(tv));               // addresses rebuilt per tile (see above)
+            const int l15 = tv & 15, q = (tv & 63) >> 4, tid = tv;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    const int drow = wc * 64 + j * 32 + nf * 16 + l15;
+                    const float bias = p.bias[tn0 + drow];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf) {
+                            const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
+                            const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
+                            const f32x4_t a = acc[i][mf][j][nf];
+                            *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
+                                make_uint2(pack_bf16x2(a[0] + bias, a[1] + bias),
+                                           pack_bf16x2(a[2] + bias, a[3] + bias));
+                        }
+                }
+            __syncthreads();
+            if (p.vt_perm && (p.tokens & 15)) {
+                const int c8r = tid & 63;
+                for (int it = 0; it < 32; ++it) {
+                    const int r = it * 8 + (tid >> 6);
+                    const int m = tm0 + c8r * 4, nv = tn0 + r - 2 * p.D;
+                    if (m >= p.M) continue;
+                    const int b = m / p.tokens, t = m % p.tokens;
+                    bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + attn_perm16(t);
+                    *reinterpret_cast<uint2*>(dst) =
+                        *reinterpret_cast<const uint2*>(smem + r * 512 + ((c8r ^ ((r & 7) << 1)) << 3));
+                }
+            } else {
+                const int c16 = tid & 31;
+                for (int it = 0; it < 16; ++it) {
+                    const int r = it * 16 + (tid >> 5);
+                    const int m = tm0 + c16 * 8, nv = tn0 + r - 2 * p.D;
+                    if (m >= p.M) continue;
+                    const int b = m / p.tokens, t = m % p.tokens;
+                    bf16_t* dst = p.vt + ((size_t)(b * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + t;
+                    const char* src = smem + r * 512 + ((c16 ^ (r & 7)) << 4);
+                    if (t + 8 <= p.tokens && m + 8 <= p.M && ((t & 7) == 0)) {
+                        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                    } else {
+                        for (int e = 0; e < 8 && m + e < p.M; ++e) {
+                            const int me = m + e, be = me / p.tokens, te = me % p.tokens;
+                            p.vt[((size_t)(be * heads + (nv >> 6)) * 64 + (nv & 63)) * p.npad + te] =
+                                *reinterpret_cast<const bf16_t*>(src + 2 * e);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                              // ring free again
+            if (more) {
+                G256P_OFFSETS(m0, n0)
+                G256P_PROLOGUE()
+            }
+        }
+#ifdef VT_STAMPS
+        G256P_T(sp_b) sp_epi += sp_b - sp_a;
+#endif
+    }
+#ifdef VT_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = sp_wait; d[1] = sp_epi; d[2] = sp_main; d[3] = __builtin_amdgcn_s_memtime() - sp_t0;
+    }
+#endif
+#undef G256P_BODY
+#undef G256P_TILE
+#undef G256P_OFFSETS
+#undef G256P_PROLOGUE
+}
+
+// column-group width for the persistent tile order: the divisor c of tiles_n minimising 32/c + c
+static int g256p_cgw(int tiles_n) {
+    int best = 1;
+    double cost = 1e9;
+    for (int c = 1; c <= tiles_n; ++c)
+        if (tiles_n % c == 0) {
+            const double k = 32.0 / c + c;
+            if (k < cost - 1e-9) { cost = k; best = c; }
+        }
+    return best;
+}
+
+template <int EPI>
+hipError_t prepare_persistent() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS);
+}
+
+template <int EPI>
+hipError_t launch_persistent(const GemmArgs& a, hipStream_t st) {
+    const int tiles_n = a.N / 256, tiles = ((a.M + 255) / 256) * tiles_n;
+    hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(256), dim3(512), G256P_LDS, st, a, tiles,
+                       g256p_cgw(tiles_n));
+    return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t prepare_one() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 1>),
@@ -633,6 +1032,9 @@ hipError_t gemm256_prepare() {
     if ((e = prepare_one<EPI_GELU_BF16>()) != hipSuccess) return e;
     if ((e = prepare_one<EPI_RELU_BF16>()) != hipSuccess) return e;
     if ((e = prepare_one<EPI_QKV>()) != hipSuccess) return e;
+    if ((e = prepare_persistent<EPI_GELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_persistent<EPI_RELU_BF16>()) != hipSuccess) return e;
+    if ((e = prepare_persistent<EPI_QKV>()) != hipSuccess) return e;
     return prepare_one<EPI_F32>();
 }
 
@@ -659,6 +1061,16 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t 
                 return hipErrorInvalidValue;
             break;
         default: return hipErrorInvalidValue;
+    }
+    if (ver == 3) {   // persistent: bf16 outputs, more tiles than CUs
+        const int tiles = ((a.M + 255) / 256) * (a.N / 256);
+        if (tiles <= 256) ver = 2;
+        else switch (epilogue) {
+            case EPI_GELU_BF16: return launch_persistent<EPI_GELU_BF16>(a, st);
+            case EPI_RELU_BF16: return launch_persistent<EPI_RELU_BF16>(a, st);
+            case EPI_QKV: return launch_persistent<EPI_QKV>(a, st);
+            default: ver = 2; break;
+        }
     }
     switch (epilogue) {
         case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, ver, st);

@@ -81,6 +81,7 @@ hipError_t gemm_prepare();  // once per device, before the first launch / any st
 // k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
 #define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
 #define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
+#define GEMM_CFG_256PP 19      // v2, persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)
 hipError_t gemm256_prepare();
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st);
 

@@ -34,7 +34,7 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18, 19])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, cfg, epi):
     """each tile configuration (64x64 / 128x128 with ring 2..4, and the 256x256 8-wave kernel) on a
@@ -56,7 +56,7 @@ def test_gemm_every_tile_config(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18, 19])
 def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)
     B, tokens, D = 2, 100, 768
@@ -104,7 +104,7 @@ def test_gemm256_exact_integers(gpu, M, N, K, cfg):
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
-@pytest.mark.parametrize("cfg", [17, 18])
+@pytest.mark.parametrize("cfg", [17, 18, 19])
 def test_gemm256_full_chip_exact_integers(gpu, cfg):
     """config 17 at the bench's size (30 streams: M = 21,600, fc1 shape, 1020 workgroups = 4 rounds
     on 256 CUs) with small-integer operands: every output must be the exact integer, three launches
@@ -284,7 +284,7 @@ def test_attention_uniformly_offset_scores(gpu, mode, level):
     assert np.abs(got - ref).max() < 0.02 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 17, 18])
+@pytest.mark.parametrize("cfg", [2, 3, 17, 18, 19])
 @pytest.mark.parametrize("tokens", [112, 100])
 def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     """Vt as attention mode 3 reads it: inside every group of 16 tokens OF A STREAM the 4-token runs
@@ -337,3 +337,31 @@ def test_layernorm(gpu, M, D):
     ref = (x - mean) / np.sqrt(var + 1e-6) * g + b
     got = gpu.op_layernorm(x, g, b)
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-4)
+
+
+@pytest.mark.parametrize("tokens,B", [(720, 30), (980, 9), (100, 70)])
+def test_gemm256_persistent_qkv_and_activation_full_chip(gpu, tokens, B):
+    """config 19 (persistent workgroups, wave-private epilogue, next tile's prologue in flight under
+    the epilogue) on more tiles than CUs with a ragged last row panel: the QKV epilogue (q/k row-major
+    through the wave-private path, V transposed through the ring, permuted key order) and the ReLU
+    epilogue on exact small integers; every element is compared, three launches each (a prologue
+    piece overwritten or read too early only shows under full-chip load)."""
+    rng = np.random.default_rng(tokens + B)
+    D = 768
+    M = tokens * B
+    a = rng.integers(-3, 4, size=(M, D)).astype(np.float32)
+    w = rng.integers(-3, 4, size=(3 * D, D)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=3 * D).astype(np.float32)
+    z = a @ w.T + bias                      # exact integers, |z| < 7000
+    ab, wb = _bits(gpu, a), _bits(gpu, w)
+    ref_qk = np.concatenate([bf16_round(z[:, :D] * QK_SCALE), bf16_round(z[:, D:2 * D])], axis=1)
+    v = bf16_round(z[:, 2 * D:]).reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
+    t = np.arange(tokens)
+    pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    for _ in range(3):
+        qk, vt_ = gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D, cfg=19, vt_perm=1)
+        assert np.array_equal(qk, ref_qk)
+        assert np.array_equal(vt_[:, :, pos], v)
+    ref = bf16_round(np.maximum(z, 0))
+    for _ in range(3):
+        assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=19), ref)
