@@ -411,11 +411,20 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
-                                                            int H, int npad) {
+                                                            int H, int npad, int stagger) {
     __shared__ __attribute__((aligned(16))) char smem[AT3_NS * AT3_STAGE];
+    // Three workgroups share a CU (one wave of each per SIMD). Dispatched together and running the
+    // same code they sit in the same phase of the step at the same time, so their MFMA, softmax-VALU
+    // and memory parts add up on the SIMD instead of overlapping (profiles/README.md). `stagger`
+    // delays the workgroups of the first residency wave by 0, 1/3 and 2/3 of a step.
+    if (stagger) {
+        const int k = (int)(blockIdx.x / 256u) % 3;
+        for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -514,65 +523,130 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
         // s = K Q^T - m_run (log2 units): two independent accumulation chains
         const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                                0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        f32x16_t s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
-        f32x16_t s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
+        f32x16_t s0, s1;
+        if constexpr (SPLIT) {              // chain a completes first: its softmax starts under chain b
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
 #pragma unroll
-        for (int ks = 1; ks < 4; ++ks) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+            for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+        } else {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
+            }
         }
+        if constexpr (SPLIT) {
+            // One softmax per 32 keys, in the order QK(a) QK(b) | softmax(a) | P.V(a) | softmax(b) |
+            // P.V(b): the QK MFMAs of the second half are in the matrix pipe while the VALU works on
+            // the first half's scores, and the first half's P.V MFMAs while it works on the second
+            // half's - MFMA and VALU time of ONE wave overlap instead of relying on the other two
+            // waves of the SIMD being in a different phase (they are not: all workgroups start
+            // together and run the same code). Each half takes its own window decision AFTER the
+            // previous half's P.V MFMAs were issued (they complete before a rescale touches O), the
+            // textbook order at 32-key granularity.
+#define AT3_HALF(S, KOFF, FIRST_HALF, G0)                                                          \
+    {                                                                                              \
+        if (kt == nt - 1 && (tokens & 63) != 0) {                                                  \
+            const int key0 = kt * 64 + (KOFF) + 4 * half;                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
+                if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
+        }                                                                                          \
+        if (shifted) {                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
+        }                                                                                          \
+        float mx = max3f(S[0], S[1], S[2]);                                                        \
+        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mx = max3f(mx, S[r], S[r + 1]);          \
+        mx = xhalf_max(fmaxf(mx, S[15]));                                                          \
+        const bool first = (FIRST_HALF) && kt == 0;                                                \
+        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {                          \
+            const float dm = first ? mx : fmaxf(mx, 0.0f);                                         \
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);                        \
+            m_run += dm;                                                                           \
+            shifted = true;                                                                        \
+            osum[0] *= alpha;                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+                o0[r] *= alpha; o1[r] *= alpha;                                                    \
+                S[r] -= dm;                                                                        \
+            }                                                                                      \
+        }                                                                                          \
+        bf16x8_t pa, pb;                                                                           \
+        {                                                                                          \
+            union { uint32_t u[4]; bf16x8_t v; } c0, c1;                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[2 * e]), __builtin_amdgcn_exp2f(S[2 * e + 1])); \
+                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[8 + 2 * e]), __builtin_amdgcn_exp2f(S[8 + 2 * e + 1])); \
+            }                                                                                      \
+            pa = c0.v; pb = c1.v;                                                                  \
+        }                                                                                          \
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0], pa, o0, 0, 0, 0);                    \
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0], pa, o1, 0, 0, 0);                    \
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);                   \
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0 + 1], pb, o0, 0, 0, 0);                \
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0 + 1], pb, o1, 0, 0, 0);                \
+        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);                   \
+    }
+            AT3_HALF(s0, 0, true, 0)
+            AT3_HALF(s1, 32, false, 2)
+#undef AT3_HALF
+        } else {
         if (kt == nt - 1 && (tokens & 63) != 0) {      // block-uniform: keys >= tokens -> -inf
-            const int key0 = kt * 64 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2);
-                if (key >= tokens) s0[r] = -INFINITY;
-                if (key + 32 >= tokens) s1[r] = -INFINITY;
+                const int key0 = kt * 64 + 4 * half;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2);
+                    if (key >= tokens) s0[r] = -INFINITY;
+                    if (key + 32 >= tokens) s1[r] = -INFINITY;
+                }
             }
-        }
-        if (shifted) {                      // wave-uniform, rare: scores relative to the moved reference
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }
-        }
-        // ---- online softmax over the 64 keys of the step (per lane: one query, 32 scores) ----
-        float mx = max3f(s0[0], s0[1], s0[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = max3f(mx, s0[r], s0[r + 1]);
-        mx = max3f(mx, s0[15], s1[0]);
-#pragma unroll
-        for (int r = 1; r < 15; r += 2) mx = max3f(mx, s1[r], s1[r + 1]);
-        mx = fmaxf(mx, s1[15]);
-        mx = xhalf_max(mx);                 // max of (score - m_run) over the query's 64 keys
-        const bool first = kt == 0;
-        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {   // wave-uniform, rare
-            const float dm = first ? mx : fmaxf(mx, 0.0f);          // m_new - m_run, per lane
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);   // O and the sum are 0 in step 0
-            m_run += dm;
-            shifted = true;
-            osum[0] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha; o1[r] *= alpha;
-                s0[r] -= dm; s1[r] -= dm;
+            if (shifted) {                      // wave-uniform, rare: scores relative to the moved reference
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }
             }
-        }
-        bf16x8_t pf[4];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            union { uint32_t u[4]; bf16x8_t v; } c0, c1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s0[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s0[8 * g + 2 * e + 1]));
-                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s1[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s1[8 * g + 2 * e + 1]));
+            // ---- online softmax over the 64 keys of the step (per lane: one query, 32 scores) ----
+            float mx = max3f(s0[0], s0[1], s0[2]);
+    #pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = max3f(mx, s0[r], s0[r + 1]);
+            mx = max3f(mx, s0[15], s1[0]);
+    #pragma unroll
+            for (int r = 1; r < 15; r += 2) mx = max3f(mx, s1[r], s1[r + 1]);
+            mx = fmaxf(mx, s1[15]);
+            mx = xhalf_max(mx);                 // max of (score - m_run) over the query's 64 keys
+            const bool first = kt == 0;
+            if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {   // wave-uniform, rare
+                const float dm = first ? mx : fmaxf(mx, 0.0f);          // m_new - m_run, per lane
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);   // O and the sum are 0 in step 0
+                m_run += dm;
+                shifted = true;
+                osum[0] *= alpha;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha; o1[r] *= alpha;
+                    s0[r] -= dm; s1[r] -= dm;
+                }
             }
-            pf[g] = c0.v;
-            pf[2 + g] = c1.v;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
-            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
+            bf16x8_t pf[4];
+    #pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                union { uint32_t u[4]; bf16x8_t v; } c0, c1;
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s0[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s0[8 * g + 2 * e + 1]));
+                    c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(s1[8 * g + 2 * e]), __builtin_amdgcn_exp2f(s1[8 * g + 2 * e + 1]));
+                }
+                pf[g] = c0.v;
+                pf[2 + g] = c1.v;
+            }
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
+            }
         }
         sbase = sbase + AT3_STAGE >= AT3_NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
     }
@@ -621,7 +695,7 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
     const int nqb = (tokens + 31) / 32;
     if (mode < 0) mode = attention_pick_mode(tokens, npad);
     if (mode >= 2 && npad % 64 != 0) return hipErrorInvalidValue;
-    if (mode == 3 && tokens % 4 != 0) return hipErrorInvalidValue;
+    if (mode >= 3 && tokens % 4 != 0) return hipErrorInvalidValue;
     if (mode == 0) {
         hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
                            tokens, H, npad);
@@ -632,8 +706,11 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
         hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
     } else if (mode == 3) {
-        hipLaunchKernelGGL(attention_dma_kernel, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad);
+        hipLaunchKernelGGL(attention_dma_kernel<false>, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
+        hipLaunchKernelGGL(attention_dma_kernel<true>, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
     } else {
         return hipErrorInvalidValue;
     }

@@ -98,7 +98,7 @@ hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int
 // and whether it wants Vt with the permuted key order (mode 3). The QKV GEMM that feeds it must be
 // given the same vt_perm.
 int attention_pick_mode(int tokens, int npad);
-inline int attention_vt_perm(int mode) { return mode == 3 ? 1 : 0; }
+inline int attention_vt_perm(int mode) { return mode >= 3 ? 1 : 0; }
 // position of key t inside its group of 16 in the permuted Vt layout: bits 2 and 3 swapped
 __host__ __device__ inline int attn_perm16(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
