@@ -88,7 +88,7 @@ EXPORTS = [
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
-    "vt_op_attention_bench", "vt_op_layernorm",
+    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench",
 ]
 
 
@@ -172,6 +172,7 @@ def lib():
     L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
     L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
+    L.vt_op_nv12_to_rgb8_bench.argtypes = [c_int, c_int, c_int, c_int, fp]
     _lib = L
     return L
 
@@ -590,6 +591,13 @@ def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0, mode=-1):
 def op_attention_bench(B, N, H, mode=-1, iters=30, device=0) -> float:
     us = c_float()
     _check(lib().vt_op_attention_bench(device, B, N, H, mode, iters, byref(us)))
+    return float(us.value)
+
+
+def op_nv12_to_rgb8_bench(w, h, iters=50, device=0) -> float:
+    """mean microseconds per launch of the whole-frame NV12 -> RGB8 converter (device-resident)"""
+    us = c_float()
+    _check(lib().vt_op_nv12_to_rgb8_bench(device, w, h, iters, byref(us)))
     return float(us.value)
 
 

@@ -1610,6 +1610,31 @@ int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iter
     return VT_OK;
 } VT_NOTHROW_INT
 
+int vt_op_nv12_to_rgb8_bench(int device_id, int w, int h, int iters, float* us_out) try {
+    if (w < 2 || h < 2 || w > 16384 || h > 16384 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    const size_t in_bytes = nv12_bytes_read(w, h) + 16, out_bytes = (size_t)w * h * 3;
+    DevBuf din, dout;
+    HIPCHK(din.alloc(in_bytes)); HIPCHK(dout.alloc(out_bytes));
+    std::vector<uint8_t> host(in_bytes);
+    uint32_t seed = 2463534242u;
+    for (auto& v : host) { seed ^= seed << 13; seed ^= seed >> 17; seed ^= seed << 5; v = (uint8_t)seed; }
+    HIPCHK(hipMemcpy(din.p, host.data(), in_bytes, hipMemcpyHostToDevice));
+    for (int i = 0; i < 3; ++i) HIPCHK(launch_nv12_to_rgb8((const uint8_t*)din.p, w, h, (uint8_t*)dout.p, nullptr));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIPCHK(launch_nv12_to_rgb8((const uint8_t*)din.p, w, h, (uint8_t*)dout.p, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_out = ms * 1000.0f / iters;
+    return VT_OK;
+} VT_NOTHROW_INT
+
 int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta, float* y, int M, int D) try {
     if (!x || !gamma || !beta || !y || M <= 0 || D % 128) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;

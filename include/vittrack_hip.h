@@ -328,6 +328,11 @@ int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, co
  * mode 0 key-split, 1 independent waves, 2 LDS-shared tiles, 3 LDS-DMA ring (permuted Vt),
  * <0 the launcher's choice. */
 int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out);
+/* Kernel-timing helper: mean microseconds per launch of the whole-frame NV12 -> RGB8 converter
+ * (the reference's nv12_full_to_rgb_parallel, src/nv12_convert.rs:46-92) on a device-resident
+ * w x h frame of random bytes (HIP events around `iters` launches). Algorithmic traffic is
+ * 1.5 + 3 bytes per pixel. */
+int vt_op_nv12_to_rgb8_bench(int device_id, int w, int h, int iters, float* us_out);
 /* y[M,D] (bf16 widened) = LayerNorm(x[M,D] f32; gamma, beta, eps=1e-6) */
 int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta,
                     float* y, int M, int D);
