@@ -70,7 +70,66 @@ __global__ __launch_bounds__(256) void nv12_to_rgb8_kernel(const uint8_t* __rest
     }
 }
 
+// Wide variant for w % 16 == 0 (1080p: 1920, 4K: 3840): one lane converts a 16 x 2 pixel block - the
+// reference's own unit of work is the row PAIR that shares one UV row (src/nv12_convert.rs:59-65).
+// Per lane: two 16-B Y loads and ONE 16-B UV load (8 U,V pairs serve 32 pixels), six 16-B stores
+// (48 B of RGB per row): every access is a full dwordx4 and a wave touches 1 KiB of contiguous Y /
+// 3 KiB of contiguous RGB per row, against 4-B loads and 12-B stores in the general kernel (measured
+// there: 2.4 TB/s at 1080p, 3.8 TB/s at 4K of the ~6.3 TB/s a copy reaches). Same integer arithmetic.
+__global__ __launch_bounds__(256) void nv12_to_rgb8_wide_kernel(const uint8_t* __restrict__ nv12, int w,
+                                                                int h, uint8_t* __restrict__ rgb) {
+    const int bpr = w >> 4;                       // 16-pixel blocks per row
+    const int row_pairs = (h + 1) >> 1;
+    const long total = (long)bpr * row_pairs;
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)w * h;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (long)gridDim.x * blockDim.x) {
+        const int rp = (int)(g / bpr), col0 = (int)(g % bpr) << 4;
+        const uint4 uv = *reinterpret_cast<const uint4*>(uvp + (size_t)rp * w + col0);
+        const uint32_t uvw[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int row = 2 * rp + r2;
+            if (row >= h) break;                  // odd height: the last pair has one row
+            const uint4 y4 = *reinterpret_cast<const uint4*>(yp + (size_t)row * w + col0);
+            const uint32_t yw[4] = {y4.x, y4.y, y4.z, y4.w};
+            uint32_t o[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {         // 4 pixels = one Y dword and one UV dword (2 pairs)
+                int r[4], gg[4], b[4];
+                const int u0 = uvw[q] & 255, v0 = (uvw[q] >> 8) & 255, u1 = (uvw[q] >> 16) & 255, v1 = uvw[q] >> 24;
+                yuv_to_rgb(yw[q] & 255, u0, v0, r[0], gg[0], b[0]);
+                yuv_to_rgb((yw[q] >> 8) & 255, u0, v0, r[1], gg[1], b[1]);
+                yuv_to_rgb((yw[q] >> 16) & 255, u1, v1, r[2], gg[2], b[2]);
+                yuv_to_rgb(yw[q] >> 24, u1, v1, r[3], gg[3], b[3]);
+                o[3 * q + 0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+                o[3 * q + 1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+                o[3 * q + 2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+            }
+            uint4* dst = reinterpret_cast<uint4*>(rgb + ((size_t)row * w + col0) * 3);
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+        }
+    }
+}
+
 hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st) {
+    // 16-B accesses need 16-B aligned planes: the UV plane starts at w*h, rows are w bytes
+    // below ~16 Mpx the conversion is a 4-10 us kernel bounded by ramp-up, and the 4-pixel kernel's 16x
+    // more lanes fill the chip sooner (measured: 1080p 3.9 vs 4.7 us, 4K 9.9 vs 10.2 us); the wide
+    // kernel is for larger surfaces (8K: 4.95 TB/s)
+    const bool wide = (size_t)w * h >= ((size_t)16 << 20) && (w % 16) == 0 && (((size_t)w * h) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(nv12) % 16) == 0 && (reinterpret_cast<uintptr_t>(rgb) % 16) == 0;
+    if (wide) {
+        const long total = (long)(w >> 4) * ((h + 1) >> 1);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(nv12_to_rgb8_wide_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
+        return hipGetLastError();
+    }
     const long total = (long)((w + 3) >> 2) * h;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest

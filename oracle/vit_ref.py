@@ -218,6 +218,9 @@ def gelu(x):
 QK_SCALE = np.float32(0.125 * 1.4426950408889634)   # 1/sqrt(64) * log2(e): float32(log2 e) / 8
 
 
+SOFTMAX_REF = "max"    # diagnostic switch (tools/diag_taps.py): "zero" = no max subtraction
+
+
 def attention(q, k, v, heads):
     """q,k,v [N, H*64] float32 holding bf16 values; q pre-scaled by QK_SCALE, so q.k is the softmax
     exponent in log2 units -> [N, H*64] f32. The probabilities are rounded to bf16 for the P.V
@@ -226,7 +229,7 @@ def attention(q, k, v, heads):
     for h in range(heads):
         sl = slice(h * 64, (h + 1) * 64)
         s = q[:, sl] @ k[:, sl].T
-        m = s.max(axis=1, keepdims=True)
+        m = s.max(axis=1, keepdims=True) if SOFTMAX_REF == "max" else np.float32(0.0)
         p = bf16r(np.exp2((s - m).astype(np.float32)).astype(np.float32))
         l = p.sum(axis=1, keepdims=True, dtype=np.float32)
         out[:, sl] = (p @ v[:, sl]) / l
