@@ -115,13 +115,14 @@ def main():
     mi = grp.model_info()
 
     # ---- synthetic clip: R frames of a closed path, resident in HBM; stream i runs it with a phase
-    sc = vt.synth.MovingSquare(fw, fh, sq, seed=rank, path="circle", period=R,
+    plan = vd.plan_rank(rank, world, B, R)
+    sc = vt.synth.MovingSquare(fw, fh, sq, seed=plan["clip_seed"], path="circle", period=R,
                                amp=3.8 * R / (2 * np.pi))
     host = np.stack([sc.frame_nv12(t) for t in range(R)])
     clip = torch.from_numpy(host).to(dev)
     fbytes = host.shape[1]
     base = clip.data_ptr()
-    phase = [(i * R) // B for i in range(B)]
+    phase = plan["phase"]
     frames_at = []
     for t in range(R):
         frames_at.append([vt.frame_nv12(base + ((t + phase[i]) % R) * fbytes,
@@ -157,11 +158,9 @@ def main():
     res = wait_all()
     torch.cuda.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dt = vd.aggregate_max_time(dt, device=dev)
-    total_frames = world * B * K
-    fps = total_frames / dt
+    dt_local = time.perf_counter() - t0
+    agg = vd.aggregate_throughput(B * K, dt_local, device=dev if world > 1 else "cpu")
+    dt, total_frames, fps = agg["seconds"], agg["frames"], agg["frames_per_s"]
 
     # sanity: every stream really tracked every frame, and still sits on the square
     t_last = W + K - 1

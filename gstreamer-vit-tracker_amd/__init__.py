@@ -89,6 +89,7 @@ EXPORTS = [
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench",
+    "vt_rccl_unique_id", "vt_broadcast_weights_rccl", "vt_free_device_blob",
 ]
 
 
@@ -173,6 +174,11 @@ def lib():
     L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
     L.vt_op_nv12_to_rgb8_bench.argtypes = [c_int, c_int, c_int, c_int, fp]
+    L.vt_rccl_unique_id.argtypes = [u8p]
+    L.vt_broadcast_weights_rccl.argtypes = [u8p, c_int, c_int, c_int, c_char_p, POINTER(c_void_p),
+                                            POINTER(c_size_t)]
+    L.vt_free_device_blob.argtypes = [c_int, c_void_p]
+    L.vt_free_device_blob.restype = None
     _lib = L
     return L
 
@@ -208,6 +214,28 @@ def export_dmabuf(d_ptr: int, nbytes: int, device: int = 0) -> int:
     fd = c_int(-1)
     _check(lib().vt_export_dmabuf(device, d_ptr, nbytes, byref(fd)))
     return fd.value
+
+
+def rccl_unique_id() -> bytes:
+    """rank 0: the 128-byte ncclUniqueId the host ships to the other ranks"""
+    buf = (c_uint8 * 128)()
+    _check(lib().vt_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def broadcast_weights_rccl(unique_id: bytes, world: int, rank: int, device: int,
+                           weights_path: str | None):
+    """vt_broadcast_weights_rccl: -> (device pointer, nbytes); release with free_device_blob"""
+    idb = (c_uint8 * 128)(*unique_id)
+    p, n = c_void_p(), c_size_t()
+    _check(lib().vt_broadcast_weights_rccl(idb, world, rank, device,
+                                           weights_path.encode() if weights_path else None,
+                                           byref(p), byref(n)))
+    return p.value, n.value
+
+
+def free_device_blob(ptr: int, device: int = 0):
+    lib().vt_free_device_blob(device, ptr)
 
 
 def device_count() -> int:

@@ -42,3 +42,31 @@ def aggregate_max_time(seconds: float, device="cpu") -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- what bench.py does per rank (kept here so the world-size-2 gloo test covers it) -------------
+
+def plan_rank(rank: int, world: int, streams_per_gpu: int, ring: int) -> dict:
+    """Work of one rank of the weak-scaling bench: every rank tracks `streams_per_gpu` independent
+    streams of its OWN synthetic clip (seed = rank, so no two ranks see the same pixels); stream i
+    of a rank starts `phase[i]` frames into the clip's closed path. Nothing here depends on another
+    rank's data: ranks exchange only the start-up weight blob and, at the end, their wall times."""
+    if not (0 <= rank < world) or streams_per_gpu < 1 or ring < 1:
+        raise ValueError("bad rank / world / streams / ring")
+    return {"clip_seed": rank, "phase": [(i * ring) // streams_per_gpu for i in range(streams_per_gpu)],
+            "global_stream_ids": [rank * streams_per_gpu + i for i in range(streams_per_gpu)]}
+
+
+def aggregate_throughput(local_frames: int, local_seconds: float, device="cpu") -> dict:
+    """Whole-job throughput as the bench contract defines it: frames of ALL ranks / MAX over ranks of
+    the wall time of the timed region. One all_reduce(SUM) and one all_reduce(MAX), outside the
+    timed region."""
+    if dist.is_available() and dist.is_initialized():
+        f = torch.tensor([float(local_frames)], dtype=torch.float64, device=device)
+        t = torch.tensor([local_seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        frames, seconds = float(f.item()), float(t.item())
+    else:
+        frames, seconds = float(local_frames), float(local_seconds)
+    return {"frames": frames, "seconds": seconds, "frames_per_s": frames / seconds}

@@ -146,6 +146,25 @@ int vt_init_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w,
 int vt_update_nv12_device(vt_tracker* t, const void* d_y, const void* d_uv, int w, int h,
                           int y_stride, int uv_stride, vt_result* out);
 
+/* ---- start-up weight broadcast over RCCL, for hosts without Python ------------------------------
+ * The path shards by stream (one process / host thread per GPU, no per-frame exchange); its only
+ * collective is the weight broadcast at start-up. librccl is loaded lazily
+ * (dlopen; symbols already in the process - e.g. PyTorch's bundled copy - are used first), so the
+ * library has no link-time dependency on it. Protocol, one caller per GPU:
+ *   rank 0        vt_rccl_unique_id(id)           128 opaque bytes (ncclUniqueId); the HOST ships
+ *                                                 them to the other ranks (file, socket, env, ...)
+ *   every rank    vt_broadcast_weights_rccl(id, world, rank, device, path, &d_blob, &bytes)
+ *                                                 rank 0 reads `path` (ignored elsewhere); one
+ *                                                 ncclBroadcast of the size, one of the bytes
+ *   every rank    vt_create_from_device_blob / vt_group_create_from_device_blob(d_blob, bytes, ...)
+ *   every rank    vt_free_device_blob(device, d_blob)
+ * VT_ERR_NO_DEVICE if librccl cannot be loaded, VT_ERR_HIP for RCCL errors (text in vt_last_error). */
+#define VT_RCCL_ID_BYTES 128
+int vt_rccl_unique_id(uint8_t id_out[VT_RCCL_ID_BYTES]);
+int vt_broadcast_weights_rccl(const uint8_t id[VT_RCCL_ID_BYTES], int world, int rank, int device_id,
+                              const char* weights_path, void** d_blob_out, size_t* bytes_out);
+void vt_free_device_blob(int device_id, void* d_blob);
+
 /* ---- B streams on one GPU (one stream per camera; no cross-stream data flow) ------------ */
 
 /* VT_PIX_YUY2: packed 4:2:2, bytes Y0 U Y1 V per pixel pair (the format the reference's IR

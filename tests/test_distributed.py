@@ -22,7 +22,9 @@ def _worker(rank, world, port, blob_path, q):
         digest = hashlib.sha256(t.numpy().tobytes()).hexdigest()
         shard = vd.shard_streams(5, rank, world)
         agg = vd.aggregate_max_time(0.5 + rank)
-        q.put((rank, digest, t.numel(), shard, agg))
+        plan = vd.plan_rank(rank, world, 6, 64)
+        thr = vd.aggregate_throughput(6 * 10, 0.5 + rank)       # bench.py's own aggregation
+        q.put((rank, digest, t.numel(), shard, agg, plan, thr))
     finally:
         dist.destroy_process_group()
 
@@ -48,6 +50,14 @@ def test_weight_broadcast_and_stream_sharding_gloo(vt, weights_tiny):
     assert sorted(s0 + s1) == list(range(5)) and abs(len(s0) - len(s1)) <= 1
     # timing is the max over ranks
     assert got[0][4] == got[1][4] == pytest.approx(1.5)
+    # bench.py's per-rank plan: own clip per rank, disjoint global stream ids, same phases
+    p0, p1 = got[0][5], got[1][5]
+    assert p0["clip_seed"] != p1["clip_seed"] and p0["phase"] == p1["phase"] == [0, 10, 21, 32, 42, 53]
+    assert sorted(p0["global_stream_ids"] + p1["global_stream_ids"]) == list(range(12))
+    # whole-job throughput = frames of all ranks / slowest rank's time, identical on every rank
+    for g in got:
+        assert g[6]["frames"] == 120 and g[6]["seconds"] == pytest.approx(1.5)
+        assert g[6]["frames_per_s"] == pytest.approx(80.0)
 
 
 def test_shard_streams_properties(vt):
@@ -60,3 +70,27 @@ def test_shard_streams_properties(vt):
                 all_ += s
                 assert len(s) in (n // world, n // world + 1)
             assert sorted(all_) == list(range(n))
+
+
+def test_plan_and_aggregate_single_process(vt):
+    import gstreamer_vit_tracker_amd.distributed as vd
+    p = vd.plan_rank(3, 8, 60, 64)
+    assert p["clip_seed"] == 3 and len(p["phase"]) == 60 and p["phase"][0] == 0 and max(p["phase"]) < 64
+    assert p["global_stream_ids"][0] == 180
+    with pytest.raises(ValueError):
+        vd.plan_rank(8, 8, 60, 64)
+    a = vd.aggregate_throughput(600, 0.1)            # no process group: the local numbers
+    assert a == {"frames": 600.0, "seconds": 0.1, "frames_per_s": 6000.0}
+
+
+def test_rccl_entry_points_fail_cleanly_without_a_gpu(vt):
+    """vt_broadcast_weights_rccl / vt_rccl_unique_id exist in the C ABI (a non-Python host's path to
+    the start-up broadcast); without a GPU they return a status code."""
+    import numpy as np
+    if vt.device_count() > 0:
+        pytest.skip("GPU present: covered by tests/test_gpu_host.py")
+    with pytest.raises(vt.VtError) as e:
+        vt.broadcast_weights_rccl(bytes(128), 1, 0, 0, "/nonexistent.vtw")
+    assert e.value.code in (-2, -3)
+    with pytest.raises(vt.VtError):
+        vt.broadcast_weights_rccl(bytes(128), 2, 5, 0, None)       # rank out of range

@@ -1,6 +1,8 @@
 """The reference's per-frame call sequence (probe closure, /root/reference/src/pipeline.rs:67-122)
 replayed through the C++ host mirror on top of the HIP library, against the Python restatement of
 the control layer on top of the oracle tracker: same commands, same frames, same states and boxes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -85,3 +87,31 @@ def test_host_nv12_full_to_rgb_through_host_lib(gpu, oracle):
     assert rc == 0
     ref_rgb, _ = oracle.nv12_to_rgb8(buf, w, h, 2)
     assert np.array_equal(out, ref_rgb)
+
+
+def test_rccl_weight_broadcast_without_python_collectives(gpu, weights_tiny):
+    """vt_rccl_unique_id + vt_broadcast_weights_rccl (direct ncclBroadcast through a dlopen'ed
+    librccl - the path a non-Python host takes) at world size 1 on this
+    one-GPU box: the blob that arrives in HBM must be the file, and a group built from it must track
+    exactly like one built from the file."""
+    import torch
+    uid = gpu.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ptr, nbytes = gpu.broadcast_weights_rccl(uid, 1, 0, 0, weights_tiny)
+    try:
+        assert nbytes == os.path.getsize(weights_tiny)
+        g = gpu.Group(n_streams=1, device_blob=(ptr, nbytes))    # validates every tensor of the blob
+        assert g.model_info().weight_bytes == nbytes
+    finally:
+        gpu.free_device_blob(ptr)
+    ref = gpu.Group(weights_tiny, n_streams=1)
+    w, h_ = 640, 480
+    sc = gpu.synth.MovingSquare(w, h_, 64, seed=12)
+    for t in range(3):
+        d = torch.from_numpy(sc.frame_nv12(t)).cuda()
+        fr = [gpu.frame_nv12(d.data_ptr(), d.data_ptr() + w * h_, w, h_)]
+        if t == 0:
+            for grp in (g, ref):
+                grp.init_device(0, fr[0], gpu.BBox.new(*sc.gt_box(0)))
+        ra, rb = g.update_device(fr)[0], ref.update_device(fr)[0]
+        assert ra.bbox == rb.bbox and ra.score == rb.score
