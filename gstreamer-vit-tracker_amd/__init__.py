@@ -42,7 +42,7 @@ class CConfig(Structure):
     _fields_ = [("struct_size", c_uint32), ("success_threshold", c_float), ("use_graph", c_int32),
                 ("n_streams", c_int32), ("max_frame_width", c_int32),
                 ("max_frame_height", c_int32), ("max_device_mib", c_int32),
-                ("reserved", c_int32 * 7)]
+                ("host_window_margin_pct", c_int32), ("reserved", c_int32 * 6)]
 
 
 class CModelInfo(Structure):
@@ -84,7 +84,8 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_recommended_streams", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_recommended_streams", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
+    "vt_group_host_redos", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
@@ -148,6 +149,9 @@ def lib():
     L.vt_export_dmabuf.argtypes = [c_int, c_void_p, c_size_t, POINTER(c_int)]
     L.vt_group_init_host.argtypes = [c_void_p, c_int, POINTER(CFrame), CBBox]
     L.vt_group_update_host.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
+    L.vt_group_enqueue_host.argtypes = [c_void_p, POINTER(CFrame), c_int]
+    L.vt_group_wait_next.argtypes = [c_void_p, POINTER(CResult), c_int]
+    L.vt_group_host_redos.argtypes = [c_void_p]
     L.vt_group_hip_stream.argtypes = [c_void_p]
     L.vt_group_hip_stream.restype = c_void_p
     L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
@@ -255,7 +259,7 @@ def _f32(a):
 
 
 def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, max_h=0,
-                max_device_mib=0) -> CConfig:
+                max_device_mib=0, host_window_margin_pct=0) -> CConfig:
     c = CConfig()
     lib().vt_config_default(byref(c))
     c.success_threshold = success_threshold
@@ -263,6 +267,7 @@ def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, ma
     c.n_streams = n_streams
     c.max_frame_width, c.max_frame_height = max_w, max_h
     c.max_device_mib = max_device_mib
+    c.host_window_margin_pct = host_window_margin_pct
     return c
 
 
@@ -420,10 +425,13 @@ class Group:
 
     def __init__(self, weights_path: str | None = None, n_streams: int = 1, device: int = 0,
                  success_threshold: float = -1.0, use_graph: bool = True,
-                 device_blob: tuple[int, int] | None = None, max_device_mib: int = 0):
+                 device_blob: tuple[int, int] | None = None, max_device_mib: int = 0,
+                 host_window_margin_pct: int = 0):
         self._h = c_void_p()
         self._owner = None
-        cfg = make_config(success_threshold, use_graph, n_streams, max_device_mib=max_device_mib)
+        self._keep = {}
+        cfg = make_config(success_threshold, use_graph, n_streams, max_device_mib=max_device_mib,
+                          host_window_margin_pct=host_window_margin_pct)
         if device_blob is not None:
             ptr, nbytes = device_blob
             _check(lib().vt_group_create_from_device_blob(ptr, nbytes, device, byref(cfg),
@@ -511,6 +519,31 @@ class Group:
         out = (CResult * len(pairs))()
         _check(lib().vt_group_update_host(self._h, arr, len(pairs), out))
         return [TrackResult(r) for r in out]
+
+    def enqueue_host(self, frames):
+        """pipelined host pass: returns once the windows are packed and the upload + pass are
+        enqueued; collect with wait_next(). The frames must stay alive and unchanged until then
+        (this wrapper keeps references)."""
+        pairs = [self._host_frame(fr) for fr in frames]
+        arr = (CFrame * len(pairs))(*[p[0] for p in pairs])
+        _check(lib().vt_group_enqueue_host(self._h, arr, len(pairs)))
+        if not hasattr(self, "_keep") or self._keep is None:
+            self._keep = {}
+        self._keep[self._keep.get("seq", 0)] = pairs
+        self._keep["seq"] = self._keep.get("seq", 0) + 1
+
+    def wait_next(self):
+        n = self.streams
+        out = (CResult * n)()
+        _check(lib().vt_group_wait_next(self._h, out, n))
+        if getattr(self, "_keep", None):
+            done = self._keep.get("done", 0)
+            self._keep.pop(done, None)
+            self._keep["done"] = done + 1
+        return [TrackResult(r) for r in out]
+
+    def host_redos(self) -> int:
+        return lib().vt_group_host_redos(self._h)
 
     def profile_device(self, frames, iters=5):
         arr = self._arr(frames)

@@ -139,7 +139,7 @@ hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, 
 }
 
 // frame pixel (px,py) as float RGB; outside the frame -> 0 (zero padding)
-__device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, float* rgb) {
+__device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, float* rgb, int& miss) {
     if (px < 0 || py < 0 || px >= f.w || py >= f.h) {
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
         return;
@@ -150,6 +150,7 @@ __device__ __forceinline__ void fetch_rgb(const FrameDesc& f, int px, int py, fl
     // never an out-of-bounds read. The library's own window planner always covers the crop.
     if ((unsigned)sx >= (unsigned)f.ww || (unsigned)sy >= (unsigned)f.wh) {
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        miss = 1;
         return;
     }
     if (f.fmt == VT_PIX_RGB8) {
@@ -200,10 +201,12 @@ __global__ __launch_bounds__(256) void preproc_kernel(const FrameDesc* __restric
     const float wy = fy - fy0, wx = fx - fx0;
     const int iy = (int)fy0, ix = (int)fx0;
     float p00[3], p01[3], p10[3], p11[3];
-    fetch_rgb(f, ix, iy, p00);
-    fetch_rgb(f, ix + 1, iy, p01);
-    fetch_rgb(f, ix, iy + 1, p10);
-    fetch_rgb(f, ix + 1, iy + 1, p11);
+    int miss = 0;
+    fetch_rgb(f, ix, iy, p00, miss);
+    fetch_rgb(f, ix + 1, iy, p01, miss);
+    fetch_rgb(f, ix, iy + 1, p10, miss);
+    fetch_rgb(f, ix + 1, iy + 1, p11, miss);
+    if (miss && !is_template) s.window_miss = s.frames_done + 1;   // every writer stores the same value
     const int grid = size / patch;
     const int token = (oy / patch) * grid + (ox / patch);
     const int kin = (oy % patch) * patch + (ox % patch);

@@ -34,7 +34,11 @@ struct StreamState {
     int32_t last_idx;        // argmax cell of the last update
     float last_fbox[4];      // unrounded clipped box of the last update
     float last_score;
-    int32_t pad[3];
+    // index (= frames_done + 1 at the time) of the last pass in which the crop needed a pixel that
+    // lies inside the frame but outside the window the caller stored: such samples read as black, so
+    // a host that uploaded a SPECULATIVE window (vt_group_enqueue_host) must redo that pass
+    int32_t window_miss;
+    int32_t pad[2];
 };
 
 struct ModelDims {

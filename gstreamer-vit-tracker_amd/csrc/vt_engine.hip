@@ -152,6 +152,24 @@ struct Engine {
     StreamState* h_states_all = nullptr;  // pinned mirror of d_states after the last pass
     int max_w = 3840, max_h = 2160;
     size_t max_device_bytes = 0;    // vt_config.max_device_mib (0: no limit but free memory)
+    // host-side copy of the stream states after the last pass the HOST has collected (window planning
+    // reads this, never a pinned buffer a running pass may still write)
+    std::vector<StreamState> known;
+    // pipelined host passes (vt_group_enqueue_host / vt_group_wait_next): two slots, each with its own
+    // pinned + device arena, result buffers, state snapshot and events; uploads go on copy_stream
+    struct HostSlot {
+        uint8_t *d_arena = nullptr, *h_arena = nullptr;
+        size_t bytes = 0;
+        vt_result* h_res = nullptr;
+        StreamState *h_st = nullptr, *d_snap = nullptr;
+        hipEvent_t up_ev = nullptr, done_ev = nullptr;
+        std::vector<vt_frame> host;     // the caller's frames, valid until the pass is collected
+        bool pending = false, speculative = false, redone = false;
+    } hs[2];
+    hipStream_t copy_stream = nullptr;
+    unsigned host_seq = 0, host_collected = 0;   // pipelined passes enqueued / collected
+    unsigned host_redos = 0;                      // passes redone because a speculative window missed
+    float margin = 0.75f;                         // speculative enlargement of the crop side
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
 
@@ -190,6 +208,17 @@ void Engine::destroy() {
     if (h_state) (void)hipHostFree(h_state);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_states_all) (void)hipHostFree(h_states_all);
+    for (HostSlot& sl : hs) {
+        if (sl.d_arena) (void)hipFree(sl.d_arena);
+        if (sl.h_arena) (void)hipHostFree(sl.h_arena);
+        if (sl.h_res) (void)hipHostFree(sl.h_res);
+        if (sl.h_st) (void)hipHostFree(sl.h_st);
+        if (sl.d_snap) (void)hipFree(sl.d_snap);
+        if (sl.up_ev) (void)hipEventDestroy(sl.up_ev);
+        if (sl.done_ev) (void)hipEventDestroy(sl.done_ev);
+        sl = HostSlot();
+    }
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
     for (int i = 0; i < RING; ++i)
         if (ring_ev[i]) (void)hipEventDestroy(ring_ev[i]);
     if (stream) (void)hipStreamDestroy(stream);
@@ -376,6 +405,7 @@ int Engine::alloc_buffers() {
     memset(h_results, 0, sizeof(vt_result) * B);
     for (int i = 0; i < RING; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
     h_initialized.assign(B, 0);
+    known.assign((size_t)B, StreamState{});
     return VT_OK;
 }
 
@@ -610,6 +640,7 @@ int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
     HIPCHK(launch_preproc(d_frames, d_states, d_patches, d, b, 1, true, stream));
     HIPCHK(hipStreamSynchronize(stream));
     h_states_all[b] = *h_state;
+    known[b] = *h_state;
     h_initialized[b] = 1;
     return VT_OK;
 }
@@ -643,6 +674,8 @@ int Engine::wait(vt_result* out, int n) {
     HIPCHK(hipStreamSynchronize(stream));
     if (out)
         for (int b = 0; b < n; ++b) out[b] = h_results[b];
+    if (host_seq == host_collected)                 // no pipelined pass owns the stream states
+        for (int b = 0; b < B; ++b) known[b] = h_states_all[b];
     return VT_OK;
 }
 
@@ -710,6 +743,8 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
             if (cfg->max_frame_width > 0) e->max_w = cfg->max_frame_width;
             if (cfg->max_frame_height > 0) e->max_h = cfg->max_frame_height;
             if (cfg->max_device_mib > 0) e->max_device_bytes = (size_t)cfg->max_device_mib << 20;
+            if (cfg->host_window_margin_pct > 0) e->margin = std::min(cfg->host_window_margin_pct, 400) / 100.0f;
+            else if (cfg->host_window_margin_pct < 0) e->margin = 0.0f;
         }
         if ((rc = e->alloc_buffers())) break;
     } while (0);
@@ -911,11 +946,13 @@ int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_res
     if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "update_host: need exactly %d frames", e->B);
     for (int b = 0; b < n; ++b)
         if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
+    if (e->host_seq != e->host_collected)
+        return set_err(VT_ERR_INVALID_ARG, "update_host: collect the pipelined passes first (vt_group_wait_next)");
     DEVICE_SCOPE(e->device);
-    HIPCHK(hipStreamSynchronize(e->stream));     // last pass done: its boxes are in h_states_all
+    if (int rc = e->wait(nullptr, 0)) return rc;   // last pass done: its boxes are in `known`
     std::vector<vt_frame> dev((size_t)n);
     std::vector<float> boxes((size_t)n * 4);
-    for (int b = 0; b < n; ++b) memcpy(&boxes[(size_t)b * 4], e->h_states_all[b].box, 4 * sizeof(float));
+    for (int b = 0; b < n; ++b) memcpy(&boxes[(size_t)b * 4], e->known[b].box, 4 * sizeof(float));
     if (int rc = stage_host_frames(e, host_frames, n, reinterpret_cast<const float(*)[4]>(boxes.data()), dev.data()))
         return rc;
     if (int rc = e->enqueue(dev.data(), n)) return rc;
@@ -948,6 +985,7 @@ int vt_group_set_state_box(vt_group* g, int stream, const float* box4) try {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->d_states[stream].box, box4, 4 * sizeof(float), hipMemcpyHostToDevice));
     memcpy(e->h_states_all[stream].box, box4, 4 * sizeof(float));
+    memcpy(e->known[stream].box, box4, 4 * sizeof(float));
     return VT_OK;
 } VT_NOTHROW_INT
 
@@ -1091,8 +1129,10 @@ struct HostWin {
     size_t bytes, uv_off;
 };
 
+// `grow`: enlargement of the crop side for a SPECULATIVE window (the box of the pass that is still
+// running is not known): 0 = the exact crop
 static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
-                       int s0, int s1, const float* box, HostWin* win) {
+                       int s0, int s1, const float* box, float grow, HostWin* win) {
     if (!p0 || w < 16 || h < 16) return set_err(VT_ERR_INVALID_ARG, "null frame or size < 16");
     if (w > e->max_w || h > e->max_h)
         return set_err(VT_ERR_INVALID_ARG, "frame %dx%d exceeds configured max %dx%d", w, h, e->max_w, e->max_h);
@@ -1106,7 +1146,7 @@ static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_
         return set_err(VT_ERR_INVALID_ARG, "unknown pixel format %d", fmt);
     }
     // window = search crop (factor 4; it contains the factor-2 template crop) + bilinear margin
-    const float side = 4.0f * sqrtf(fmaxf(box[2] * box[3], 1.0f));
+    const float side = 4.0f * sqrtf(fmaxf(box[2] * box[3], 1.0f)) * (1.0f + grow);
     const float cx = box[0] + 0.5f * box[2], cy = box[1] + 0.5f * box[3];
     long x_lo = (long)floorf(cx - 0.5f * side) - 4, x_hi = (long)ceilf(cx + 0.5f * side) + 4;
     long y_lo = (long)floorf(cy - 0.5f * side) - 4, y_hi = (long)ceilf(cy + 0.5f * side) + 4;
@@ -1132,23 +1172,33 @@ static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_
     return VT_OK;
 }
 
-// pinned + device arena of at least `need` bytes (grown with the stream idle)
-static int ensure_stage(Engine* e, size_t need) {
-    if (need <= e->stage_bytes) return VT_OK;
+// where the packed windows of one call go: a pinned host arena, its device twin, and the stream the
+// single H2D copy is enqueued on
+struct Arena {
+    uint8_t** d;
+    uint8_t** h;
+    size_t* cap;
+    hipStream_t copy_on;
+};
+
+// pinned + device arena of at least `need` bytes (grown only while nothing uses it)
+static int ensure_arena(Engine* e, const Arena& a, size_t need) {
+    if (need <= *a.cap) return VT_OK;
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->d_stage) { (void)hipFree(e->d_stage); e->d_stage = nullptr; }
-    if (e->h_pack) { (void)hipHostFree(e->h_pack); e->h_pack = nullptr; }
-    e->stage_bytes = 0;
+    if (a.copy_on != e->stream) HIPCHK(hipStreamSynchronize(a.copy_on));
+    if (*a.d) { (void)hipFree(*a.d); *a.d = nullptr; }
+    if (*a.h) { (void)hipHostFree(*a.h); *a.h = nullptr; }
+    *a.cap = 0;
     const size_t cap = need + need / 2 + 4096;
-    HIPCHK(hipMalloc((void**)&e->d_stage, cap));
-    HIPCHK(hipHostMalloc((void**)&e->h_pack, cap));
-    e->stage_bytes = cap;
+    HIPCHK(hipMalloc((void**)a.d, cap));
+    HIPCHK(hipHostMalloc((void**)a.h, cap));
+    *a.cap = cap;
     return VT_OK;
 }
 
-static void pack_window(Engine* e, const HostWin& wn, size_t off, vt_frame* f) {
-    uint8_t* dst = e->h_pack + off;
+static void pack_window(const Arena& a, const HostWin& wn, size_t off, vt_frame* f) {
+    uint8_t* dst = *a.h + off;
     memset(f, 0, sizeof(*f));
     f->width = wn.w; f->height = wn.h; f->format = wn.fmt;
     f->origin_x = wn.x_lo; f->origin_y = wn.y_lo;
@@ -1159,7 +1209,7 @@ static void pack_window(Engine* e, const HostWin& wn, size_t off, vt_frame* f) {
         const size_t rb = (size_t)wn.ww * bpp;
         for (int r = 0; r < wn.wh; ++r)
             memcpy(dst + r * rb, wn.p0 + (size_t)(wn.y_lo + r) * wn.s0 + (size_t)wn.x_lo * bpp, rb);
-        f->plane0 = e->d_stage + off; f->stride0 = (int)rb;
+        f->plane0 = *a.d + off; f->stride0 = (int)rb;
     } else {
         const int uvw = (wn.ww + 1) & ~1, uvh = (wn.wh + 1) / 2;
         for (int r = 0; r < wn.wh; ++r)
@@ -1169,34 +1219,41 @@ static void pack_window(Engine* e, const HostWin& wn, size_t off, vt_frame* f) {
         for (int r = 0; r < uvh; ++r)
             memcpy(dst + wn.uv_off + (size_t)r * uvw, wn.p1 + (size_t)(wn.y_lo / 2 + r) * wn.s1 + wn.x_lo,
                    (size_t)uv_avail);
-        f->plane0 = e->d_stage + off; f->plane1 = e->d_stage + off + wn.uv_off;
+        f->plane0 = *a.d + off; f->plane1 = *a.d + off + wn.uv_off;
         f->stride0 = wn.ww; f->stride1 = uvw;
     }
 }
 
-// n host frames -> n device frame descriptors (windows packed, one H2D copy enqueued on the stream).
+// n host frames -> n device frame descriptors (windows packed, ONE H2D copy enqueued on a.copy_on).
 // boxes[i]: the box that decides stream i's window (the new box at init, the last state at update).
-static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float (*boxes)[4], vt_frame* dev) {
+static int stage_host_frames_to(Engine* e, const Arena& a, const vt_frame* host, int n, const float (*boxes)[4],
+                                float grow, vt_frame* dev, size_t* bytes_out) {
     std::vector<HostWin> wins((size_t)n);
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         const vt_frame& hf = host[i];
         if (int rc = plan_window(e, hf.format, (const uint8_t*)hf.plane0, (const uint8_t*)hf.plane1, hf.width,
-                                 hf.height, hf.stride0, hf.stride1, boxes[i], &wins[i]))
+                                 hf.height, hf.stride0, hf.stride1, boxes[i], grow, &wins[i]))
             return rc;
         total += wins[i].bytes;
     }
-    if (int rc = ensure_stage(e, total)) return rc;
+    if (int rc = ensure_arena(e, a, total)) return rc;
     DEVICE_SCOPE(e->device);
-    // the previous call's copy out of the pinned arena has finished: every host entry point waits
-    // for its pass before returning
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
-        pack_window(e, wins[i], off, &dev[i]);
+        pack_window(a, wins[i], off, &dev[i]);
         off += wins[i].bytes;
     }
-    HIPCHK(hipMemcpyAsync(e->d_stage, e->h_pack, total, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(*a.d, *a.h, total, hipMemcpyHostToDevice, a.copy_on));
+    if (bytes_out) *bytes_out = total;
     return VT_OK;
+}
+
+// the synchronous entry points: one arena, copy on the engine's own stream (every such call waits
+// for its pass before returning, so the arena is free again at the next call)
+static int stage_host_frames(Engine* e, const vt_frame* host, int n, const float (*boxes)[4], vt_frame* dev) {
+    const Arena a{&e->d_stage, &e->h_pack, &e->stage_bytes, e->stream};
+    return stage_host_frames_to(e, a, host, n, boxes, 0.0f, dev, nullptr);
 }
 
 static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t* p1, int w, int h,
@@ -1207,6 +1264,118 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
     float b4[1][4] = {{box[0], box[1], box[2], box[3]}};
     return stage_host_frames(e, &hf, 1, b4, f);
 }
+
+// ---- pipelined host passes -------------------------------------------------------------------------
+
+static int host_slot_prepare(Engine* e, Engine::HostSlot& sl) {
+    if (sl.h_res) return VT_OK;
+    DEVICE_SCOPE(e->device);
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void**)&sl.h_res, sizeof(vt_result) * e->B));
+    HIPCHK(hipHostMalloc((void**)&sl.h_st, sizeof(StreamState) * e->B));
+    HIPCHK(hipMalloc((void**)&sl.d_snap, sizeof(StreamState) * e->B));
+    HIPCHK(hipEventCreateWithFlags(&sl.up_ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&sl.done_ev, hipEventDisableTiming));
+    return VT_OK;
+}
+
+// exact (non-speculative) synchronous pass over `host` with the states the device holds now; results
+// and states land in the slot's buffers
+static int host_pass_exact_sync(Engine* e, Engine::HostSlot& sl) {
+    const int n = e->B;
+    std::vector<vt_frame> dev((size_t)n);
+    std::vector<float> boxes((size_t)n * 4);
+    for (int b = 0; b < n; ++b) memcpy(&boxes[(size_t)b * 4], e->known[b].box, 4 * sizeof(float));
+    if (int rc = stage_host_frames(e, sl.host.data(), n, reinterpret_cast<const float(*)[4]>(boxes.data()), dev.data()))
+        return rc;
+    if (int rc = e->enqueue(dev.data(), n)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(sl.h_res, e->h_results, sizeof(vt_result) * n);
+    memcpy(sl.h_st, e->h_states_all, sizeof(StreamState) * n);
+    for (int b = 0; b < n; ++b) e->known[b] = e->h_states_all[b];
+    sl.redone = true;
+    return VT_OK;
+}
+
+int vt_group_enqueue_host(vt_group* g, const vt_frame* host_frames, int n) try {
+    if (!g || !host_frames) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "enqueue_host: need exactly %d frames", e->B);
+    for (int b = 0; b < n; ++b)
+        if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
+    const unsigned outstanding = e->host_seq - e->host_collected;
+    if (outstanding >= 2)
+        return set_err(VT_ERR_INVALID_ARG, "enqueue_host: two passes outstanding, call vt_group_wait_next first");
+    DEVICE_SCOPE(e->device);
+    Engine::HostSlot& sl = e->hs[e->host_seq & 1];
+    if (int rc = host_slot_prepare(e, sl)) return rc;
+    if (outstanding == 0) {
+        // nothing of ours is running: make sure nothing else is either, then the boxes are exact
+        if (int rc = e->wait(nullptr, 0)) return rc;
+    }
+    sl.host.assign(host_frames, host_frames + n);
+    sl.speculative = outstanding == 1;
+    sl.redone = false;
+    std::vector<vt_frame> dev((size_t)n);
+    std::vector<float> boxes((size_t)n * 4);
+    for (int b = 0; b < n; ++b) memcpy(&boxes[(size_t)b * 4], e->known[b].box, 4 * sizeof(float));
+    const Arena a{&sl.d_arena, &sl.h_arena, &sl.bytes, e->copy_stream};
+    if (int rc = stage_host_frames_to(e, a, host_frames, n, reinterpret_cast<const float(*)[4]>(boxes.data()),
+                                      sl.speculative ? e->margin : 0.0f, dev.data(), nullptr))
+        return rc;
+    HIPCHK(hipEventRecord(sl.up_ev, e->copy_stream));
+    HIPCHK(hipStreamWaitEvent(e->stream, sl.up_ev, 0));          // the pass starts behind ITS upload only
+    HIPCHK(hipMemcpyAsync(sl.d_snap, e->d_states, sizeof(StreamState) * n, hipMemcpyDeviceToDevice, e->stream));
+    if (int rc = e->enqueue(dev.data(), n)) return rc;
+    HIPCHK(hipMemcpyAsync(sl.h_res, e->d_results, sizeof(vt_result) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(sl.h_st, e->d_states, sizeof(StreamState) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(sl.done_ev, e->stream));
+    sl.pending = true;
+    e->host_seq += 1;
+    return VT_OK;
+} VT_NOTHROW_INT
+
+int vt_group_wait_next(vt_group* g, vt_result* out, int n) try {
+    if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    Engine* e = g->e;
+    if (e->host_seq == e->host_collected) return set_err(VT_ERR_INVALID_ARG, "wait_next: no pass outstanding");
+    DEVICE_SCOPE(e->device);
+    Engine::HostSlot& sl = e->hs[e->host_collected & 1];
+    Engine::HostSlot& younger = e->hs[(e->host_collected + 1) & 1];
+    const bool has_younger = e->host_seq - e->host_collected == 2;
+    if (!sl.redone) {
+        HIPCHK(hipEventSynchronize(sl.done_ev));
+        bool miss = false;
+        if (sl.speculative)
+            for (int b = 0; b < e->B; ++b)
+                miss = miss || (sl.h_st[b].window_miss != 0 && sl.h_st[b].window_miss == sl.h_st[b].frames_done);
+        if (miss) {
+            // a stream moved out of its speculative window: rewind to the snapshot taken before this
+            // pass and redo it - and the pass queued behind it, which consumed its wrong states -
+            // with exact windows
+            e->host_redos += 1;
+            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipMemcpy(e->d_states, sl.d_snap, sizeof(StreamState) * e->B, hipMemcpyDeviceToDevice));
+            std::vector<StreamState> st((size_t)e->B);
+            HIPCHK(hipMemcpy(st.data(), sl.d_snap, sizeof(StreamState) * e->B, hipMemcpyDeviceToHost));
+            for (int b = 0; b < e->B; ++b) e->known[b] = st[b];
+            if (int rc = host_pass_exact_sync(e, sl)) return rc;
+            if (has_younger)
+                if (int rc = host_pass_exact_sync(e, younger)) return rc;
+        }
+    }
+    if (out)
+        for (int b = 0; b < std::min(n, e->B); ++b) out[b] = sl.h_res[b];
+    // boxes the next window is planned around: this pass's - unless a younger pass was redone just
+    // now, whose states are newer (host_pass_exact_sync set `known` already)
+    if (!(has_younger && younger.redone))
+        for (int b = 0; b < e->B; ++b) e->known[b] = sl.h_st[b];
+    sl.pending = false;
+    e->host_collected += 1;
+    return VT_OK;
+} VT_NOTHROW_INT
+
+int vt_group_host_redos(const vt_group* g) { return g ? (int)g->e->host_redos : 0; }
 
 static int do_init(vt_tracker* t, const vt_frame* f, vt_bbox box) { return t->e->init_stream(0, f, box); }
 static int do_update(vt_tracker* t, const vt_frame* f, vt_result* out) {
@@ -1227,7 +1396,7 @@ int vt_update_rgb8(vt_tracker* t, const uint8_t* rgb, int w, int h, int stride_b
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
+    if (int rc = stage_host_frame(t->e, VT_PIX_RGB8, rgb, nullptr, w, h, stride_bytes, 0, t->e->known[0].box, &f)) return rc;
     return do_update(t, &f, out);
 } VT_NOTHROW_INT
 int vt_init_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_bytes, vt_bbox box) try {
@@ -1241,7 +1410,7 @@ int vt_update_yuy2(vt_tracker* t, const uint8_t* yuy2, int w, int h, int stride_
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, t->e->h_states_all[0].box, &f)) return rc;
+    if (int rc = stage_host_frame(t->e, VT_PIX_YUY2, yuy2, nullptr, w, h, stride_bytes, 0, t->e->known[0].box, &f)) return rc;
     return do_update(t, &f, out);
 } VT_NOTHROW_INT
 int vt_init_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, int h, int y_stride,
@@ -1257,7 +1426,7 @@ int vt_update_nv12(vt_tracker* t, const uint8_t* y, const uint8_t* uv, int w, in
     if (!t) return set_err(VT_ERR_INVALID_ARG, "null tracker");
     if (!t->e->h_initialized[0]) return set_err(VT_ERR_NOT_INITIALIZED, "update before init");
     vt_frame f;
-    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, t->e->h_states_all[0].box, &f)) return rc;
+    if (int rc = stage_host_frame(t->e, VT_PIX_NV12, y, uv, w, h, y_stride, uv_stride, t->e->known[0].box, &f)) return rc;
     return do_update(t, &f, out);
 } VT_NOTHROW_INT
 

@@ -78,7 +78,10 @@ typedef struct vt_config {
     int32_t max_device_mib;    /* > 0: refuse (VT_ERR_OOM) to create an engine whose weights +
                                 * activations need more HBM than this; 0: only the device's free
                                 * memory limits it (checked before anything is allocated) */
-    int32_t reserved[7];
+    int32_t host_window_margin_pct; /* vt_group_enqueue_host: enlargement of the speculative window in
+                                * percent of the crop side; 0 -> 75 (see there); < 0 -> none (tests:
+                                * every moving target then takes the redo path) */
+    int32_t reserved[6];
 } vt_config;
 #define VT_MAX_STREAMS 1024
 
@@ -216,6 +219,24 @@ void* vt_group_hip_stream(vt_group* g);
  * cross PCIe in one copy. Synchronous: the caller's buffers may be reused on return. */
 int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_bbox box);
 int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_result* out);
+/* Pipelined form of the same: the upload of pass t+1 overlaps the compute of pass t.
+ *   vt_group_enqueue_host(frames of t+1)   packs the windows into one of two pinned arenas and copies
+ *                                          them on a separate copy stream, then enqueues the pass
+ *                                          behind that copy; returns without waiting
+ *   vt_group_wait_next(out)                waits for the OLDEST pass not yet collected, returns its
+ *                                          results
+ * At most two passes may be outstanding (one running, one queued); the host frames of an outstanding
+ * pass must stay valid and unchanged until its vt_group_wait_next returns.
+ * While a pass is running its boxes are not known, so the window of the next frame is cut around the
+ * last KNOWN box, enlarged to cover a target that moves by a quarter of the search crop and grows by a
+ * quarter in one frame (1.75x the crop side). The pixel kernel flags a pass that needed a pixel outside
+ * the window it was given; vt_group_wait_next then restores the stream states from a device-side
+ * snapshot and redoes that pass (and the one queued behind it) with exact windows, so the results are
+ * always those of the full frames. (host -> tracker: src/pipeline.rs:95-101 maps the buffer on the CPU) */
+int vt_group_enqueue_host(vt_group* g, const vt_frame* host_frames, int n);
+int vt_group_wait_next(vt_group* g, vt_result* out, int n);
+/* passes vt_group_wait_next had to redo because a speculative window missed (since creation) */
+int vt_group_host_redos(const vt_group* g);
 
 /* ---- dma-buf ingest ------------------------------------------------------------------------
  * The reference's capture side can hand out dma-bufs (v4l2src io-mode=dmabuf, src/pipeline_ir.rs:24)

@@ -536,3 +536,43 @@ def test_strided_nv12_rgb8_yuy2_patch_matrix_vs_oracle(gpu, oracle, weights_tiny
         d = torch.from_numpy(qb).cuda()
         got, keep = run_device(gpu.CFrame(d.data_ptr(), None, w, h, qs, 0, gpu.PIX_YUY2, 0, 0, 0, 0, 0))
     assert np.array_equal(got, want), "YUY2 strided"
+
+
+# ---- upload of pass t+1 overlapped with the compute of pass t ------------------
+
+@pytest.mark.parametrize("margin_pct,expect_redo", [(0, False), (-1, True)])
+def test_pipelined_host_passes_equal_synchronous_ones(gpu, weights_tiny, margin_pct, expect_redo):
+    """vt_group_enqueue_host / vt_group_wait_next (speculative windows, copy stream, two arenas) give
+    exactly the results of the synchronous vt_group_update_host on the same frames - with the default
+    enlargement (no redo on this clip) and with the enlargement switched off, where every moving
+    target leaves its speculative window and the snapshot/redo path runs."""
+    B, w, h, n = 3, 640, 480, 24
+    scs = [gpu.synth.MovingSquare(w, h, 64, seed=60 + i) for i in range(B)]
+    pipe = gpu.Group(weights_tiny, n_streams=B, host_window_margin_pct=margin_pct)
+    sync = gpu.Group(weights_tiny, n_streams=B)
+    frames = [[gpu.NV12Frame(sc.frame_nv12(t), w, h) if i != 1 else sc.frame_rgb8(t)
+               for i, sc in enumerate(scs)] for t in range(n)]
+    for i in range(B):
+        box = gpu.BBox.new(*scs[i].gt_box(0))
+        pipe.init_host(i, frames[0][i], box)
+        sync.init_host(i, frames[0][i], box)
+    want = [sync.update_host(frames[t]) for t in range(n)]
+    got = []
+    pipe.enqueue_host(frames[0])
+    for t in range(1, n):
+        pipe.enqueue_host(frames[t])          # upload of t overlaps the pass of t-1
+        got.append(pipe.wait_next())          # results of t-1
+    got.append(pipe.wait_next())
+    for t in range(n):
+        for i in range(B):
+            assert got[t][i].bbox == want[t][i].bbox and got[t][i].score == want[t][i].score, (t, i)
+            assert got[t][i].success
+    assert (pipe.host_redos() > 0) == expect_redo, pipe.host_redos()
+    with pytest.raises(gpu.VtError):
+        pipe.wait_next()                      # nothing outstanding
+    pipe.enqueue_host(frames[0]); pipe.enqueue_host(frames[1])
+    with pytest.raises(gpu.VtError):
+        pipe.enqueue_host(frames[2])          # two passes outstanding
+    pipe.wait_next(); pipe.wait_next()
+    # the synchronous entry point still works afterwards and continues the same state chain
+    assert len(pipe.update_host(frames[2])) == B
