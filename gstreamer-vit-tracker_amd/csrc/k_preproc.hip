@@ -222,14 +222,105 @@ __global__ __launch_bounds__(256) void preproc_kernel(const FrameDesc* __restric
     }
 }
 
+// Wide-store variant: one lane produces PX horizontally adjacent output pixels of one patch row for
+// all three channels and writes each channel's run with ONE store (PX = 8: 16 B, patch % 8 == 0;
+// PX = 2: 4 B, even patch sizes such as 14). The patch matrix is the dominant traffic of this stage
+// (0.88 MB out per stream against a ~0.1 MB source window that stays in L1/L2): with one lane per pixel
+// the stores were 2-B scatters, 48 per 32-B segment. Same per-pixel arithmetic and tap order as
+// preproc_kernel (bit-exact with oracle/vt_oracle.c); neighbouring pixels re-fetch shared taps from
+// L1. grid: (ceil(size*size/PX/256), nb).
+template <int PX>
+__global__ __launch_bounds__(256) void preproc_wide_kernel(const FrameDesc* __restrict__ frames,
+                                                           StreamState* __restrict__ states,
+                                                           bf16_t* __restrict__ patches, int b0,
+                                                           int size, int patch, int kpad, int ntok,
+                                                           int row_off, float factor, float na0,
+                                                           float na1, float na2, float nb0, float nb1,
+                                                           float nb2, int is_template) {
+    const int b = b0 + blockIdx.y;
+    const FrameDesc f = frames[b];
+    StreamState& s = states[b];
+    // crop geometry — same operations, same order as vto_crop_geometry (oracle/vt_oracle.c)
+    const float bx = s.box[0], by = s.box[1], bw = s.box[2], bh = s.box[3];
+    const float area = bw * bh;
+    const float side = factor * sqrtf(area);
+    const float scale = side / (float)size;
+    const float cx = bx + 0.5f * bw;
+    const float cy = by + 0.5f * bh;
+    const float half = 0.5f * side;
+    const float x0m = (cx - half) - 0.5f;
+    const float y0m = (cy - half) - 0.5f;
+    const int grp = blockIdx.x * blockDim.x + threadIdx.x;        // group of PX pixels
+    if (grp == 0 && !is_template) {
+        s.geo[0] = x0m; s.geo[1] = y0m; s.geo[2] = scale; s.geo[3] = side;
+        s.frame_w = f.w; s.frame_h = f.h;
+    }
+    const int gpr = size / PX;                                     // groups per output row
+    if (grp >= gpr * size) return;
+    const int oy = grp / gpr, ox0 = (grp % gpr) * PX;
+    const float fy = ((float)oy + 0.5f) * scale + y0m;
+    const float fy0 = floorf(fy);
+    const float wy = fy - fy0;
+    const int iy = (int)fy0;
+    const float na[3] = {na0, na1, na2}, nb[3] = {nb0, nb1, nb2};
+    bf16_t o[3][PX];
+    int miss = 0;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const float fx = ((float)(ox0 + k) + 0.5f) * scale + x0m;
+        const float fx0 = floorf(fx);
+        const float wx = fx - fx0;
+        const int ix = (int)fx0;
+        float p00[3], p01[3], p10[3], p11[3];
+        fetch_rgb(f, ix, iy, p00, miss);
+        fetch_rgb(f, ix + 1, iy, p01, miss);
+        fetch_rgb(f, ix, iy + 1, p10, miss);
+        fetch_rgb(f, ix + 1, iy + 1, p11, miss);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = p00[c] + wx * (p01[c] - p00[c]);
+            const float bot = p10[c] + wx * (p11[c] - p10[c]);
+            const float v = top + wy * (bot - top);
+            o[c][k] = f32_to_bf16(v * na[c] + nb[c]);
+        }
+    }
+    if (miss && !is_template) s.window_miss = s.frames_done + 1;   // every writer stores the same value
+    const int grid = size / patch;
+    const int token = (oy / patch) * grid + (ox0 / patch);         // PX divides patch: one token per group
+    const int kin = (oy % patch) * patch + (ox0 % patch);
+    bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        bf16_t* dst = row + c * patch * patch + kin;
+        if constexpr (PX == 8) {
+            uint4 v;
+            v.x = o[c][0] | ((uint32_t)o[c][1] << 16); v.y = o[c][2] | ((uint32_t)o[c][3] << 16);
+            v.z = o[c][4] | ((uint32_t)o[c][5] << 16); v.w = o[c][6] | ((uint32_t)o[c][7] << 16);
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            *reinterpret_cast<uint32_t*>(dst) = o[c][0] | ((uint32_t)o[c][1] << 16);
+        }
+    }
+}
+
 hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
                           const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st) {
     const int size = is_template ? d.T : d.S;
     const int row_off = is_template ? 0 : d.nt;
     const float factor = is_template ? 2.0f : 4.0f;
-    dim3 grid((size * size + 255) / 256, nb);
-    hipLaunchKernelGGL(preproc_kernel, grid, dim3(256), 0, st, frames, states, patches, b0, size,
-                       d.patch, d.kpad, d.ntok, row_off, factor, d.norm_a[0], d.norm_a[1],
-                       d.norm_a[2], d.norm_b[0], d.norm_b[1], d.norm_b[2], is_template ? 1 : 0);
+#define PRE_ARGS frames, states, patches, b0, size, d.patch, d.kpad, d.ntok, row_off, factor, d.norm_a[0], \
+                 d.norm_a[1], d.norm_a[2], d.norm_b[0], d.norm_b[1], d.norm_b[2], is_template ? 1 : 0
+    // store alignment: a run starts at element c*p*p + py*p + px0 of a row of kpad elements
+    if (d.patch % 8 == 0 && d.kpad % 8 == 0) {                 // 16-B stores
+        dim3 grid((size * size / 8 + 255) / 256, nb);
+        hipLaunchKernelGGL(preproc_wide_kernel<8>, grid, dim3(256), 0, st, PRE_ARGS);
+    } else if (d.patch % 2 == 0 && d.kpad % 2 == 0) {          // 4-B stores (patch 14)
+        dim3 grid((size * size / 2 + 255) / 256, nb);
+        hipLaunchKernelGGL(preproc_wide_kernel<2>, grid, dim3(256), 0, st, PRE_ARGS);
+    } else {
+        dim3 grid((size * size + 255) / 256, nb);
+        hipLaunchKernelGGL(preproc_kernel, grid, dim3(256), 0, st, PRE_ARGS);
+    }
+#undef PRE_ARGS
     return hipGetLastError();
 }
