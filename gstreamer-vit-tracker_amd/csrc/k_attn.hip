@@ -411,12 +411,15 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
 }
 
-template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __restrict__ qk,
+// NS: ring stages of 16 KiB (3: two tiles ahead, 48 KiB -> 3 workgroups per CU; 2: one tile ahead,
+// 32 KiB -> 4 workgroups per CU if the kernel also fits 128 registers); WPS: waves per SIMD the
+// register allocation must allow.
+template <int ORD, int NS, int WPS>
+__global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
                                                             int H, int npad, int stagger) {
-    __shared__ __attribute__((aligned(16))) char smem[AT3_NS * AT3_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[NS * AT3_STAGE];
     // Three workgroups share a CU (one wave of each per SIMD). Dispatched together and running the
     // same code they sit in the same phase of the step at the same time, so their MFMA, softmax-VALU
     // and memory parts add up on the SIMD instead of overlapping (profiles/README.md). `stagger`
@@ -496,24 +499,95 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
     bool shifted = false;                // wave-uniform: some lane's m_run != 0
     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
+    constexpr int AHEAD = NS - 1;        // tiles in flight beyond the one being computed
     AT3_STAGE_TILE(0, 0)
-    if (nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
+    if (AHEAD > 1 && nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
     int sbase = 0;                       // LDS offset of the stage holding tile kt
     for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        if (AHEAD > 1 && kt + 1 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
         // every wave's pieces of tile kt have landed, and every wave is done with tile kt-1,
-        // whose stage tile kt+2 overwrites
+        // whose stage tile kt+AHEAD overwrites
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nt) {
-            int s2base = sbase + 2 * AT3_STAGE;
-            s2base = s2base >= AT3_NS * AT3_STAGE ? s2base - AT3_NS * AT3_STAGE : s2base;
-            AT3_STAGE_TILE(kt + 2, s2base)
+        if (kt + AHEAD < nt) {
+            int s2base = sbase + AHEAD * AT3_STAGE;
+            s2base = s2base >= NS * AT3_STAGE ? s2base - NS * AT3_STAGE : s2base;
+            AT3_STAGE_TILE(kt + AHEAD, s2base)
         }
         const char* st = smem + sbase;
         const char* p0 = st + fa0; const char* p1 = st + fa1;
         const char* p2 = st + fa2; const char* p3 = st + fa3;
 #define AT3_RD(P, OFF) (*reinterpret_cast<const bf16x8_t*>((P) + (OFF)))
+        constexpr bool SPLIT = ORD == 1;
+        if constexpr (ORD == 2) {
+            // Sequential halves, every fragment loaded right before its use (scheduling regions fenced):
+            //   K(a) -> QK(a) -> softmax(a) -> V(a) -> P.V(a) -> K(b) -> QK(b) -> softmax(b) -> V(b) -> P.V(b)
+            // Peak live registers: O / row-sum accumulators 48 + Q 16 + scores 16 + P 8 + one set of 16
+            // fragment registers: the kernel fits 128 registers, i.e. FOUR workgroups per CU (with the
+            // 2-stage ring's 32 KiB). Nothing overlaps inside a wave; the other three waves of the SIMD do.
+            const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                                   0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#define AT3_SEQ_HALF(KBYTES, KOFF, FIRST_HALF, PA_, PB_)                                           \
+    {                                                                                              \
+        f32x16_t S;                                                                                \
+        {                                                                                          \
+            const bf16x8_t k0 = AT3_RD(p0, KBYTES), k1 = AT3_RD(p1, KBYTES);                       \
+            const bf16x8_t k2 = AT3_RD(p2, KBYTES), k3 = AT3_RD(p3, KBYTES);                       \
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], zero, 0, 0, 0);                 \
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], S, 0, 0, 0);                    \
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], S, 0, 0, 0);                    \
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], S, 0, 0, 0);                    \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (kt == nt - 1 && (tokens & 63) != 0) {                                                  \
+            const int key0 = kt * 64 + (KOFF) + 4 * half;                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
+                if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
+        }                                                                                          \
+        if (shifted) {                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
+        }                                                                                          \
+        float mx = max3f(S[0], S[1], S[2]);                                                        \
+        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mx = max3f(mx, S[r], S[r + 1]);          \
+        mx = xhalf_max(fmaxf(mx, S[15]));                                                          \
+        const bool first = (FIRST_HALF) && kt == 0;                                                \
+        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {                          \
+            const float dm = first ? mx : fmaxf(mx, 0.0f);                                         \
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);                        \
+            m_run += dm;                                                                           \
+            shifted = true;                                                                        \
+            osum[0] *= alpha;                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+                o0[r] *= alpha; o1[r] *= alpha;                                                    \
+                S[r] -= dm;                                                                        \
+            }                                                                                      \
+        }                                                                                          \
+        bf16x8_t pa, pb;                                                                           \
+        {                                                                                          \
+            union { uint32_t u[4]; bf16x8_t v; } c0, c1;                                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[2 * e]), __builtin_amdgcn_exp2f(S[2 * e + 1])); \
+                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[8 + 2 * e]), __builtin_amdgcn_exp2f(S[8 + 2 * e + 1])); \
+            }                                                                                      \
+            pa = c0.v; pb = c1.v;                                                                  \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        {                                                                                          \
+            const bf16x8_t va0 = AT3_RD(PA_, 8192), vb0 = AT3_RD(PA_, 12288);                      \
+            const bf16x8_t va1 = AT3_RD(PB_, 8192), vb1 = AT3_RD(PB_, 12288);                      \
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pa, o0, 0, 0, 0);                    \
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pa, o1, 0, 0, 0);                    \
+            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);               \
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pb, o0, 0, 0, 0);                    \
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pb, o1, 0, 0, 0);                    \
+            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);               \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+            AT3_SEQ_HALF(0, 0, true, p0, p1)
+            AT3_SEQ_HALF(4096, 32, false, p2, p3)
+#undef AT3_SEQ_HALF
+        } else {
         bf16x8_t kf0[4], kf1[4], vf0[4], vf1[4];
         kf0[0] = AT3_RD(p0, 0); kf0[1] = AT3_RD(p1, 0); kf0[2] = AT3_RD(p2, 0); kf0[3] = AT3_RD(p3, 0);
         kf1[0] = AT3_RD(p0, 4096); kf1[1] = AT3_RD(p1, 4096); kf1[2] = AT3_RD(p2, 4096); kf1[3] = AT3_RD(p3, 4096);
@@ -648,7 +722,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
                 osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
             }
         }
-        sbase = sbase + AT3_STAGE >= AT3_NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
+        }   // ORD != 2
+        sbase = sbase + AT3_STAGE >= NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
     }
     const float l_run = osum[0];
 
@@ -682,6 +757,11 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const bf16_t* __r
 
 // mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
 // 3 = LDS-DMA ring with permuted Vt (default when tokens % 4 == 0 and npad % 64 == 0), -1 = choose.
+// 4, 5 = measured alternatives of mode 3 kept for A/B (operator-level entry points only): 4 = one
+// softmax per 32 keys with QK(b) under softmax(a) (74 vs 70 us at 30 streams), 5 = 2-stage ring and
+// sequential halves in 119 registers = four workgroups per CU (76.8 vs 72.8 us: a fourth wave per
+// SIMD does not help - MFMA and VALU time of this instruction mix add up on a SIMD whatever the
+// number of waves; a 2-stage ring alone is as fast as the 3-stage one, 72.3 us).
 int attention_pick_mode(int tokens, int npad) {
     if (npad % 64 != 0) return 0;
     return (tokens % 4 == 0) ? 3 : 2;   // tokens % 4: the QKV epilogue's 4-token runs stay inside a stream
@@ -706,10 +786,13 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
         hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
     } else if (mode == 3) {
-        hipLaunchKernelGGL(attention_dma_kernel<false>, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
-        hipLaunchKernelGGL(attention_dma_kernel<true>, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 5) {               // 4 workgroups per CU: 2-stage ring, sequential halves in <= 128 registers
+        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else {
         return hipErrorInvalidValue;

@@ -222,7 +222,8 @@ def test_attention(gpu, B, N, H, scale, mode):
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
                                          (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
                                          (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
-def test_attention_mode3(gpu, B, N, H, scale):
+@pytest.mark.parametrize("mode", [3, 5])
+def test_attention_mode3(gpu, B, N, H, scale, mode):
     """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
     Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
     (320), more tiles than ring stages (1008), token counts that are not multiples of 16 (100, 980,
@@ -241,7 +242,7 @@ def test_attention_mode3(gpu, B, N, H, scale):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
 def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
     sequence: the reference must move and everything accumulated before be rescaled"""
@@ -261,7 +262,7 @@ def test_attention_late_maximum_rescale(gpu, mode):
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5])
 @pytest.mark.parametrize("level", [-20.0, -64.0, -150.0, 90.0])
 def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
@@ -306,7 +307,7 @@ def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
