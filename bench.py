@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--groups", type=int, default=2,
                     help="engines per GPU, each with streams/groups streams on its own HIP stream "
                          "(kernels of different groups overlap on the chip)")
+    ap.add_argument("--engines", default="",
+                    help="engine sizes instead of --groups equal ones: '30+1', or 'auto' = "
+                         "vt_plan_engines(--streams)")
     ap.add_argument("--ring", type=int, default=64, help="distinct frames kept in HBM per clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive leg")
@@ -100,17 +103,27 @@ def main():
 
     # ---- weights: rank 0 generates/reads the blob, RCCL broadcast, every rank builds from HBM ----
     wpath = vt.weights.ensure_weights(cfg_name) if rank == 0 else None
-    if B % G:
-        raise SystemExit("--streams must be a multiple of --groups")
-    Bg = B // G
+    if args.engines == "auto":
+        if args.streams <= 0:
+            raise SystemExit("--engines auto needs --streams")
+        sizes = vt.weights.plan_engines(cfg_name, args.streams)
+    elif args.engines:
+        sizes = [int(x) for x in args.engines.split("+")]
+    else:
+        if B % G:
+            raise SystemExit("--streams must be a multiple of --groups (or give --engines)")
+        sizes = [B // G] * G
+    G, B = len(sizes), sum(sizes)
+    off = [sum(sizes[:g]) for g in range(G + 1)]         # engine g holds streams off[g] .. off[g+1]
+    eng = [g for g in range(G) for _ in range(sizes[g])]  # stream -> engine
+    Bg = sizes[0]                                          # the engine whose pass is profiled below
     if world > 1:
         blob = vd.broadcast_weights(wpath, device=dev)
-        grps = [vt.Group(n_streams=Bg, device=local, use_graph=not args.eager,
-                         device_blob=(blob.data_ptr(), blob.numel())) for _ in range(G)]
+        grps = [vt.Group(n_streams=b, device=local, use_graph=not args.eager,
+                         device_blob=(blob.data_ptr(), blob.numel())) for b in sizes]
         del blob
     else:
-        grps = [vt.Group(wpath, n_streams=Bg, device=local, use_graph=not args.eager)
-                for _ in range(G)]
+        grps = [vt.Group(wpath, n_streams=b, device=local, use_graph=not args.eager) for b in sizes]
     grp = grps[0]
     mi = grp.model_info()
 
@@ -129,12 +142,12 @@ def main():
                                         base + ((t + phase[i]) % R) * fbytes + fw * fh, fw, fh)
                           for i in range(B)])
     for i in range(B):
-        grps[i // Bg].init_device(i % Bg, frames_at[0][i], vt.BBox.new(*sc.gt_box(phase[i])))
+        grps[eng[i]].init_device(i - off[eng[i]], frames_at[0][i], vt.BBox.new(*sc.gt_box(phase[i])))
 
     def enqueue_all(t):
         fr = frames_at[t % R]
         for g in range(G):
-            grps[g].enqueue_device(fr[g * Bg:(g + 1) * Bg])
+            grps[g].enqueue_device(fr[off[g]:off[g + 1]])
 
     def wait_all():
         res = []
@@ -166,7 +179,7 @@ def main():
     t_last = W + K - 1
     ious, done, succ = [], [], []
     for i in range(B):
-        st = grps[i // Bg].read_state(i % Bg)
+        st = grps[eng[i]].read_state(i - off[eng[i]])
         done.append(st["frames_done"])
         succ.append(st["success_count"])
         ious.append(iou(res[i].bbox, sc.gt_box((t_last + phase[i]) % R)))
@@ -194,7 +207,7 @@ def main():
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": wl_text, "vit_config": cfg_name, "frame": f"{fw}x{fh} NV12",
-                   "streams_per_gpu": B, "engines_per_gpu": G, "tokens": mi.tokens_template + mi.tokens_search,
+                   "streams_per_gpu": B, "engines_per_gpu": G, "engine_sizes": sizes, "tokens": mi.tokens_template + mi.tokens_search,
                    "ingest": "frames resident in HBM", "launch": "eager" if args.eager else "hipGraph",
                    "weights": "synthetic seeded encoder + fitted head (no reference weights exist)"},
         "per_stream_fps": fps / (world * B),
@@ -253,14 +266,12 @@ def main():
         import threading
         hs = args.host_steps
         hclip = [vt.NV12Frame(host[t], fw, fh) for t in range(R)]     # pageable numpy memory
-        hg = [vt.Group(wpath if world == 1 else vt.weights.ensure_weights(cfg_name), n_streams=Bg,
-                       device=local, use_graph=not args.eager) for _ in range(G)]
-        for i in range(B):
-            hg[i // Bg].init_host(i % Bg, hclip[phase[i] % R], vt.BBox.new(*sc.gt_box(phase[i])))
+        hg = [vt.Group(wpath if world == 1 else vt.weights.ensure_weights(cfg_name), n_streams=b,
+                       device=local, use_graph=not args.eager) for b in sizes]
         oks = []
 
         def frames_for(gi, t):
-            return [hclip[(t + phase[gi * Bg + j]) % R] for j in range(Bg)]
+            return [hclip[(t + phase[i]) % R] for i in range(off[gi], off[gi + 1])]
 
         def run_host(gi, n, rec, pipelined):
             ok = True
@@ -277,7 +288,9 @@ def main():
 
         def reinit():
             for i in range(B):
-                hg[i // Bg].init_host(i % Bg, hclip[phase[i] % R], vt.BBox.new(*sc.gt_box(phase[i])))
+                hg[eng[i]].init_host(i - off[eng[i]], hclip[phase[i] % R], vt.BBox.new(*sc.gt_box(phase[i])))
+
+        reinit()
 
         legs = {}
         for name, pipelined in (("sync", False), ("pipelined", True)):

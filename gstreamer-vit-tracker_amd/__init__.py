@@ -84,7 +84,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_recommended_streams", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
+    "vt_recommended_streams", "vt_plan_engines", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
     "vt_group_host_redos", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
@@ -143,6 +143,7 @@ def lib():
     L.vt_group_wait.argtypes = [c_void_p, POINTER(CResult), c_int]
     L.vt_group_update_device.argtypes = [c_void_p, POINTER(CFrame), c_int, POINTER(CResult)]
     L.vt_recommended_streams.argtypes = [POINTER(CModelInfo), c_int]
+    L.vt_plan_engines.argtypes = [POINTER(CModelInfo), c_int, POINTER(c_int), c_int]
     L.vt_import_dmabuf.argtypes = [c_int, c_int, c_size_t, POINTER(c_void_p), POINTER(c_void_p)]
     L.vt_release_dmabuf.argtypes = [c_void_p]
     L.vt_release_dmabuf.restype = None
@@ -198,6 +199,15 @@ def recommended_streams(info: "CModelInfo", max_streams: int = 128) -> int:
     return lib().vt_recommended_streams(byref(info), max_streams)
 
 
+def plan_engines(info: "CModelInfo", n_streams: int) -> list:
+    """vt_plan_engines: engine (Group) sizes for n_streams on one GPU that avoid a nearly empty GEMM round"""
+    sizes = (c_int * 8)()
+    k = lib().vt_plan_engines(byref(info), n_streams, sizes, 8)
+    if k <= 0:
+        raise ValueError(f"vt_plan_engines({n_streams}) failed")
+    return [int(sizes[i]) for i in range(k)]
+
+
 class DmaBuf:
     """a dma-buf mapped into device memory (vt_import_dmabuf); .ptr is usable as a frame plane"""
 
@@ -207,9 +217,12 @@ class DmaBuf:
         self.ptr, self.nbytes = p.value, nbytes
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib().vt_release_dmabuf(self._h)
-            self._h = c_void_p()
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                lib().vt_release_dmabuf(self._h)
+                self._h = c_void_p()
+        except TypeError:      # interpreter shutdown: module globals are already None
+            pass
 
     __del__ = close
 
@@ -347,9 +360,12 @@ class VitTrack:
         return VitTrack(model_path, **kw)
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().vt_destroy(self._h)
-            self._h = c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().vt_destroy(self._h)
+                self._h = c_void_p()
+        except TypeError:      # interpreter shutdown: module globals are already None
+            pass
 
     __del__ = close
 
@@ -450,9 +466,12 @@ class Group:
         return g
 
     def close(self):
-        if getattr(self, "_own", False) and self._h.value:
-            lib().vt_group_destroy(self._h)
-        self._h = c_void_p()
+        try:
+            if getattr(self, "_own", False) and self._h.value:
+                lib().vt_group_destroy(self._h)
+            self._h = c_void_p()
+        except TypeError:      # interpreter shutdown: module globals are already None
+            pass
 
     __del__ = close
 

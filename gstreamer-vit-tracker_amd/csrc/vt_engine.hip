@@ -875,6 +875,23 @@ int vt_recommended_streams(const vt_model_info* info, int max_streams) try {
     return 1;
 } VT_NOTHROW_INT
 
+int vt_plan_engines(const vt_model_info* info, int n_streams, int* sizes, int cap) try {
+    if (!info || !sizes || n_streams < 1 || cap < 1) return 0;
+    const int r = vt_recommended_streams(info, 128);
+    int k;                                        // engines
+    if (r <= 1 || n_streams <= r) k = 1;
+    else k = 2;
+    while ((n_streams + k - 1) / k > VT_MAX_STREAMS) ++k;
+    if (k > cap) return 0;
+    if (k == 2 && n_streams < 2 * r) {            // a full engine and the rest
+        sizes[0] = r;
+        sizes[1] = n_streams - r;
+        return 2;
+    }
+    for (int i = 0; i < k; ++i) sizes[i] = n_streams / k + (i < n_streams % k ? 1 : 0);
+    return k;
+} VT_NOTHROW_INT
+
 int vt_group_create(const char* weights_path, int device_id, const vt_config* cfg, vt_group** out) try {
     if (!weights_path || !out) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = nullptr;

@@ -106,6 +106,14 @@ int vt_device_count(void);             /* gfx950 devices visible; 0 → vt_creat
  * there is none or the model's width does not fit that kernel). No reference counterpart: the
  * reference runs one tracker per process (src/pipeline.rs:55). Needs no GPU. */
 int vt_recommended_streams(const vt_model_info* info, int max_streams);
+/* How to spread n_streams over the vt_groups ("engines") of ONE GPU so that no engine pays for an
+ * almost empty GEMM round: up to R = vt_recommended_streams() one engine; between R and 2R an engine
+ * of R plus one with the rest (their kernels overlap on the chip: 31 streams cost 172 us per frame
+ * as 30 + 1 against 197 in one engine and 164 at 30); from 2R on two engines of n/2 (three or more
+ * concurrent engines measured worse than two). Writes the engine sizes (each <= VT_MAX_STREAMS) to
+ * sizes[0..cap) and returns how many, 0 on bad arguments. No reference counterpart (one tracker per
+ * process there, src/pipeline.rs:55). Needs no GPU. */
+int vt_plan_engines(const vt_model_info* info, int n_streams, int* sizes, int cap);
 
 /* ---- single stream: the literal drop-in ------------------------------------------------ */
 

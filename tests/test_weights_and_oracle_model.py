@@ -127,6 +127,33 @@ def test_c_abi_recommended_streams_matches_python(vt):
         assert vt.recommended_streams(mi) == vt.weights.recommended_streams(name)
 
 
+def test_engine_plan_keeps_every_engine_off_the_tile_count_cliff(vt):
+    """vt_plan_engines / weights.plan_engines: n streams of one GPU over engines (Groups); sizes sum to
+    n, one engine up to the recommended batch, a full engine + the rest below twice that, then halves"""
+    assert vt.weights.plan_engines("cfg3", 1) == [1]
+    assert vt.weights.plan_engines("cfg3", 30) == [30]
+    assert vt.weights.plan_engines("cfg3", 31) == [30, 1]
+    assert vt.weights.plan_engines("cfg3", 45) == [30, 15]
+    assert vt.weights.plan_engines("cfg3", 60) == [30, 30]
+    assert vt.weights.plan_engines("cfg3", 61) == [31, 30]
+    assert vt.weights.plan_engines("cfg3", 90) == [45, 45]
+    assert vt.weights.plan_engines("tiny", 50) == [50]            # no 256-wide kernel: nothing to plan
+    assert vt.weights.plan_engines("cfg3", 3000) == [1000, 1000, 1000]
+    with pytest.raises(ValueError):
+        vt.weights.plan_engines("cfg3", 0)
+    for name in ("cfg2", "cfg3", "cfg5", "tiny"):
+        cfg = vt.weights.get_config(name)
+        mi = vt.CModelInfo()
+        mi.dim, mi.mlp_dim = cfg.dim, cfg.mlp_dim
+        mi.tokens_template, mi.tokens_search = cfg.n_t, cfg.n_s
+        for n in (1, 2, 29, 30, 31, 33, 34, 59, 60, 61, 67, 68, 133, 134, 135, 200, 1024, 1025, 2049):
+            got = vt.plan_engines(mi, n)
+            assert got == vt.weights.plan_engines(name, n), (name, n)
+            assert sum(got) == n and all(0 < g <= 1024 for g in got)
+    with pytest.raises(ValueError):
+        vt.plan_engines(mi, 0)
+
+
 def test_oracle_parser_is_independent_and_agrees_with_the_writer(vt):
     """oracle/vit_ref.py reads the blob with its own parser (no import of the product package);
     both readers must see the same header and tensors in what the product's writer emits."""
