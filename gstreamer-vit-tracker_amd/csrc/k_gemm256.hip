@@ -865,16 +865,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         if ((KB) * 16 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0; \
         if ((KB) * 16 + 8 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1; \
     }
+#ifdef VT_AB_SCALAR_GELU      /* tuning builds only: the per-element form, for A/B against the packed one */
+#define VT_GELU2(X) f32v2_t{gelu_erf((X).x), gelu_erf((X).y)}
+#else
+#define VT_GELU2(X) gelu_erf2(X)
+#endif
 #define G256P_EPI_ONE(K, J, NF, WA)                                                              \
     {                                                                                            \
-        float v[4];                                                                              \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
-            const float x = acc[(K) >> 2][(K) & 3][J][NF][e] + bias4[J][NF][e];                  \
-            if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);                              \
-            else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);                      \
+        f32v2_t v[2];                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                          \
+            const f32v2_t x = f32v2_t{acc[(K) >> 2][(K) & 3][J][NF][2 * e], acc[(K) >> 2][(K) & 3][J][NF][2 * e + 1]} + \
+                              f32v2_t{bias4[J][NF][2 * e], bias4[J][NF][2 * e + 1]};             \
+            if constexpr (EPI == EPI_GELU_BF16) v[e] = VT_GELU2(x);                              \
+            else if constexpr (EPI == EPI_RELU_BF16) v[e] = f32v2_t{fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)}; \
             else v[e] = x * scale;                                                               \
         }                                                                                        \
-        lds_write64_asm<((K) & 1) * 2048>(WA, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); \
+        lds_write64_asm<((K) & 1) * 2048>(WA, __builtin_bit_cast(uint32_t, __builtin_convertvector(v[0], bf16v2_t)), \
+                                          __builtin_bit_cast(uint32_t, __builtin_convertvector(v[1], bf16v2_t))); \
     }
 #define G256P_EPI_BLOCK(K, STAGE_STMT)                                                           \
     {                                                                                            \

@@ -26,6 +26,23 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return __builtin_fmaf(-a, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
+// The same arithmetic on two elements at once: the five polynomial steps and the final fma become
+// v_pk_fma_f32 (two f32 per lane and issue slot - the packed form is what the CU's f32 peak rate is
+// quoted on), each element's result is bit-identical to gelu_erf's. v_exp_f32, |x| and max stay
+// per element (no packed forms).
+__device__ __forceinline__ f32v2_t gelu_erf2(f32v2_t x) {
+    const f32v2_t a = {fabsf(x.x), fabsf(x.y)};
+    f32v2_t p = __builtin_elementwise_fma(f32v2_t{-0.0004733149544335902f, -0.0004733149544335902f}, a,
+                                          f32v2_t{0.007084596436470747f, 0.007084596436470747f});
+    p = __builtin_elementwise_fma(p, a, f32v2_t{-0.05182747542858124f, -0.05182747542858124f});
+    p = __builtin_elementwise_fma(p, a, f32v2_t{-0.45999234914779663f, -0.45999234914779663f});
+    p = __builtin_elementwise_fma(p, a, f32v2_t{-1.1507878303527832f, -1.1507878303527832f});
+    p = __builtin_elementwise_fma(p, a, f32v2_t{-1.000037670135498f, -1.000037670135498f});
+    const f32v2_t e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    const f32v2_t r = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+    return __builtin_elementwise_fma(-a, e, r);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");

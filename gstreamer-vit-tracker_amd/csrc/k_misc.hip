@@ -303,6 +303,12 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
         s.box[0] = (float)r.bbox.x; s.box[1] = (float)r.bbox.y;
         s.box[2] = (float)r.bbox.width; s.box[3] = (float)r.bbox.height;
     }
+    // the host's copies, straight into its pinned memory (visible to it once the pass's event or the
+    // stream synchronises; the fence orders the stores ahead of the kernel's end for every scope)
+    const PassOut po = *a.out;
+    if (po.host_results) po.host_results[b] = r;
+    if (po.host_states) po.host_states[b] = s;
+    __threadfence_system();
 }
 
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {

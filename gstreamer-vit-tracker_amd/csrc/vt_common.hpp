@@ -124,6 +124,14 @@ hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, co
 hipError_t launch_overlay_rgb(uint8_t* rgb, int width, int height, int stride, const vt_draw_cmd* d_cmds,
                               int n, hipStream_t st);
 
+// Where a pass leaves its results for the host: pinned, device-visible host memory the decode kernel
+// stores to directly (no device-to-host copy on the stream). Uploaded with the frame descriptors of
+// the pass, right behind them in the same buffer.
+struct PassOut {
+    vt_result* host_results;    // [B] or null
+    StreamState* host_states;   // [B] or null
+};
+
 struct DecodeArgs {
     const bf16_t* t3;       // [B*ns][C]
     const float* w4;        // [8][C]
@@ -132,6 +140,7 @@ struct DecodeArgs {
     float* head_out;        // [B*ns][8]
     StreamState* states;    // [B]
     vt_result* results;     // [B] (device)
+    const PassOut* out;     // device copy of this pass's PassOut
     int B, ns, grid, C;
     float success_threshold;
 };

@@ -137,7 +137,9 @@ struct Engine {
     vt_result* d_results = nullptr;
     // pinned host
     static const int RING = 8;
-    FrameDesc* h_frames = nullptr;  // [RING][B]
+    FrameDesc* h_frames = nullptr;  // [RING] blocks of B descriptors + PassOut
+    size_t frames_block_bytes() const { return sizeof(FrameDesc) * (size_t)B + sizeof(PassOut); }
+    FrameDesc* h_block(int slot) const { return (FrameDesc*)((char*)h_frames + (size_t)slot * frames_block_bytes()); }
     hipEvent_t ring_ev[RING]{};
     int ring_pos = 0;
     vt_result* h_results = nullptr;
@@ -161,7 +163,7 @@ struct Engine {
         uint8_t *d_arena = nullptr, *h_arena = nullptr;
         size_t bytes = 0;
         vt_result* h_res = nullptr;
-        StreamState *h_st = nullptr, *d_snap = nullptr;
+        StreamState* h_st = nullptr;
         hipEvent_t up_ev = nullptr, done_ev = nullptr;
         std::vector<vt_frame> host;     // the caller's frames, valid until the pass is collected
         bool pending = false, speculative = false, redone = false;
@@ -182,7 +184,9 @@ struct Engine {
     int alloc_buffers();
     int run_pass(Profiler* prof);
     int capture_graph();
-    int enqueue(const vt_frame* frames, int n);
+    // host_res / host_st: pinned buffers the pass's results and states are stored to (null: the
+    // engine's own h_results / h_states_all)
+    int enqueue(const vt_frame* frames, int n, vt_result* host_res = nullptr, StreamState* host_st = nullptr);
     int wait(vt_result* out, int n);
     int init_stream(int b, const vt_frame* f, vt_bbox box);
     const TensorRef* find(const std::string& n) const {
@@ -213,7 +217,6 @@ void Engine::destroy() {
         if (sl.h_arena) (void)hipHostFree(sl.h_arena);
         if (sl.h_res) (void)hipHostFree(sl.h_res);
         if (sl.h_st) (void)hipHostFree(sl.h_st);
-        if (sl.d_snap) (void)hipFree(sl.d_snap);
         if (sl.up_ev) (void)hipEventDestroy(sl.up_ev);
         if (sl.done_ev) (void)hipEventDestroy(sl.done_ev);
         sl = HostSlot();
@@ -395,9 +398,14 @@ int Engine::alloc_buffers() {
     HIPCHK(dalloc0(&d_col, Ms * 9 * d.C));
     HIPCHK(dalloc0(&d_headout, Ms * 8));
     HIPCHK(dalloc0(&d_states, (size_t)B));
-    HIPCHK(dalloc0(&d_frames, (size_t)B));
+    {   // B frame descriptors + the pass's PassOut behind them (one upload per pass)
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, frames_block_bytes()));
+        HIPCHK(hipMemset(p, 0, frames_block_bytes()));
+        d_frames = (FrameDesc*)p;
+    }
     HIPCHK(dalloc0(&d_results, (size_t)B));
-    HIPCHK(hipHostMalloc((void**)&h_frames, sizeof(FrameDesc) * B * RING));
+    HIPCHK(hipHostMalloc((void**)&h_frames, frames_block_bytes() * RING));
     HIPCHK(hipHostMalloc((void**)&h_results, sizeof(vt_result) * B));
     HIPCHK(hipHostMalloc((void**)&h_state, sizeof(StreamState)));
     HIPCHK(hipHostMalloc((void**)&h_states_all, sizeof(StreamState) * B));
@@ -543,15 +551,14 @@ int Engine::run_pass(Profiler* prof) {
         a.b4 = (const float*)find("head.b4")->ptr;
         a.hann = (const float*)find("hann")->ptr;
         a.head_out = d_headout; a.states = d_states; a.results = d_results;
+        a.out = (const PassOut*)(d_frames + B);
         a.B = B; a.ns = d.ns; a.grid = d.gs; a.C = d.C;
         a.success_threshold = success_threshold;
         L("decode", 2.0 * Ms * d.C * 5, (double)Ms * d.C * 2, [&] { return launch_decode(a, stream); });
     }
     if (lerr != hipSuccess)
         return set_err(VT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
-    HIPCHK(hipMemcpyAsync(h_results, d_results, sizeof(vt_result) * B, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(h_states_all, d_states, sizeof(StreamState) * B, hipMemcpyDeviceToHost, stream));
-    return VT_OK;
+    return VT_OK;     // results and states reach the host through the decode kernel's own stores (PassOut)
 }
 
 int Engine::capture_graph() {
@@ -645,7 +652,7 @@ int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
     return VT_OK;
 }
 
-int Engine::enqueue(const vt_frame* frames, int n) {
+int Engine::enqueue(const vt_frame* frames, int n, vt_result* host_res, StreamState* host_st) {
     if (!frames || n != B) return set_err(VT_ERR_INVALID_ARG, "enqueue: need exactly %d frames", B);
     for (int b = 0; b < B; ++b) {
         if (!h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d: update before init", b);
@@ -655,9 +662,10 @@ int Engine::enqueue(const vt_frame* frames, int n) {
     const int slot = ring_pos;
     ring_pos = (ring_pos + 1) % RING;
     HIPCHK(hipEventSynchronize(ring_ev[slot]));  // the copy that last used this slot is done
-    FrameDesc* hf = h_frames + (size_t)slot * B;
+    FrameDesc* hf = h_block(slot);
     for (int b = 0; b < B; ++b) to_desc(frames[b], hf + b);
-    HIPCHK(hipMemcpyAsync(d_frames, hf, sizeof(FrameDesc) * B, hipMemcpyHostToDevice, stream));
+    *(PassOut*)(hf + B) = PassOut{host_res ? host_res : h_results, host_st ? host_st : h_states_all};
+    HIPCHK(hipMemcpyAsync(d_frames, hf, frames_block_bytes(), hipMemcpyHostToDevice, stream));
     HIPCHK(hipEventRecord(ring_ev[slot], stream));
     if (use_graph && !taps) {
         if (!graph_exec)
@@ -1015,12 +1023,13 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
         if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
-    FrameDesc* hf = e->h_frames;
+    FrameDesc* hf = e->h_block(0);
     for (int b = 0; b < e->B; ++b) {
         if (int rc = check_frame(frames[b])) return rc;
         to_desc(frames[b], hf + b);
     }
-    HIPCHK(hipMemcpyAsync(e->d_frames, hf, sizeof(FrameDesc) * e->B, hipMemcpyHostToDevice, e->stream));
+    *(PassOut*)(hf + e->B) = PassOut{e->h_results, e->h_states_all};
+    HIPCHK(hipMemcpyAsync(e->d_frames, hf, e->frames_block_bytes(), hipMemcpyHostToDevice, e->stream));
     Profiler prof;
     for (int it = 0; it < iters; ++it)
         if (int rc = e->run_pass(&prof)) return rc;
@@ -1290,7 +1299,6 @@ static int host_slot_prepare(Engine* e, Engine::HostSlot& sl) {
     if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void**)&sl.h_res, sizeof(vt_result) * e->B));
     HIPCHK(hipHostMalloc((void**)&sl.h_st, sizeof(StreamState) * e->B));
-    HIPCHK(hipMalloc((void**)&sl.d_snap, sizeof(StreamState) * e->B));
     HIPCHK(hipEventCreateWithFlags(&sl.up_ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&sl.done_ev, hipEventDisableTiming));
     return VT_OK;
@@ -1342,10 +1350,7 @@ int vt_group_enqueue_host(vt_group* g, const vt_frame* host_frames, int n) try {
         return rc;
     HIPCHK(hipEventRecord(sl.up_ev, e->copy_stream));
     HIPCHK(hipStreamWaitEvent(e->stream, sl.up_ev, 0));          // the pass starts behind ITS upload only
-    HIPCHK(hipMemcpyAsync(sl.d_snap, e->d_states, sizeof(StreamState) * n, hipMemcpyDeviceToDevice, e->stream));
-    if (int rc = e->enqueue(dev.data(), n)) return rc;
-    HIPCHK(hipMemcpyAsync(sl.h_res, e->d_results, sizeof(vt_result) * n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(sl.h_st, e->d_states, sizeof(StreamState) * n, hipMemcpyDeviceToHost, e->stream));
+    if (int rc = e->enqueue(dev.data(), n, sl.h_res, sl.h_st)) return rc;   // results land in THIS slot's buffers
     HIPCHK(hipEventRecord(sl.done_ev, e->stream));
     sl.pending = true;
     e->host_seq += 1;
@@ -1367,15 +1372,13 @@ int vt_group_wait_next(vt_group* g, vt_result* out, int n) try {
             for (int b = 0; b < e->B; ++b)
                 miss = miss || (sl.h_st[b].window_miss != 0 && sl.h_st[b].window_miss == sl.h_st[b].frames_done);
         if (miss) {
-            // a stream moved out of its speculative window: rewind to the snapshot taken before this
-            // pass and redo it - and the pass queued behind it, which consumed its wrong states -
-            // with exact windows
+            // a stream moved out of its speculative window: rewind to the states this pass started
+            // from - `known`, the host's copy of the states the previous pass left (collected by the
+            // wait_next before this one) - and redo it, and the pass queued behind it, which consumed
+            // its wrong states, with exact windows
             e->host_redos += 1;
             HIPCHK(hipStreamSynchronize(e->stream));
-            HIPCHK(hipMemcpy(e->d_states, sl.d_snap, sizeof(StreamState) * e->B, hipMemcpyDeviceToDevice));
-            std::vector<StreamState> st((size_t)e->B);
-            HIPCHK(hipMemcpy(st.data(), sl.d_snap, sizeof(StreamState) * e->B, hipMemcpyDeviceToHost));
-            for (int b = 0; b < e->B; ++b) e->known[b] = st[b];
+            HIPCHK(hipMemcpy(e->d_states, e->known.data(), sizeof(StreamState) * e->B, hipMemcpyHostToDevice));
             if (int rc = host_pass_exact_sync(e, sl)) return rc;
             if (has_younger)
                 if (int rc = host_pass_exact_sync(e, younger)) return rc;
@@ -1385,8 +1388,11 @@ int vt_group_wait_next(vt_group* g, vt_result* out, int n) try {
         for (int b = 0; b < std::min(n, e->B); ++b) out[b] = sl.h_res[b];
     // boxes the next window is planned around: this pass's - unless a younger pass was redone just
     // now, whose states are newer (host_pass_exact_sync set `known` already)
-    if (!(has_younger && younger.redone))
+    if (!(has_younger && younger.redone)) {
         for (int b = 0; b < e->B; ++b) e->known[b] = sl.h_st[b];
+        memcpy(e->h_states_all, sl.h_st, sizeof(StreamState) * e->B);   // the engine's own mirrors follow
+        memcpy(e->h_results, sl.h_res, sizeof(vt_result) * e->B);
+    }
     sl.pending = false;
     e->host_collected += 1;
     return VT_OK;

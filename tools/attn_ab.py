@@ -1,7 +1,7 @@
 """A/B of attention kernel modes in one process: python tools/attn_ab.py 3,4,5,6 30 [rounds]"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 modes = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [3]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 30

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 modes = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3]
 Bs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 8, 16, 32]

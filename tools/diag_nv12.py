@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 from oracle import vit_ref as R
 w,h=64,48

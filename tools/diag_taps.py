@@ -3,7 +3,7 @@ oracle's softmax reference point at the true row maximum (the spec) and at 0 (wh
 uses inside its +-32 window): python tools/diag_taps.py cfg5"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 from oracle import vit_ref as R
 

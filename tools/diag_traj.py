@@ -1,7 +1,7 @@
 """per-frame float boxes of the HIP path and the oracle on the same clip (diagnostic)"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 from oracle import vit_ref as R
 cfg, frames, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -3,7 +3,7 @@ median and minimum microseconds per launch of each configuration on the tracker'
 shapes.  python tools/gemm_ab.py 17,18 30 [rounds]"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [17, 18]
 Bs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [30]

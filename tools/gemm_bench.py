@@ -1,6 +1,6 @@
 """GEMM tile-configuration sweep on the tracker's shapes (run on the GPU box)."""
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 names = {0: "64x64x4", 1: "128x128x3", 2: "64x64x2", 3: "128x128x2", 17: "256x256p8"}
 epi_names = {1: "resid", 2: "gelu", 4: "qkv"}

@@ -1,7 +1,7 @@
 """time vs K at fixed M, N: slope = per-K-tile cost of the main loop, intercept = prologue + epilogue
 usage: python tools/gemm_kslope.py [cfg] [M]"""
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 21600

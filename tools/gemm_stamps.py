@@ -2,7 +2,7 @@
    python gstreamer-vit-tracker_amd/build.py --stamps && VITTRACK_HIP_LIB=.../libvittrack_hip_stamps.so python tools/gemm_stamps.py 19 30
 prints (stderr of the library) per-wave mean cycles: wait / epilogue(issue) / main(compute) / total."""
 import os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 os.environ.setdefault("VITTRACK_HIP_LIB", os.path.join("gstreamer-vit-tracker_amd", "libvittrack_hip_stamps.so"))
 import gstreamer_vit_tracker_amd as vt
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [19]

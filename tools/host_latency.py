@@ -2,7 +2,7 @@
 update(&ArrayView3<u8>) on a 1080p RGB8 frame and the fused NV12 form."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 w, h = 1920, 1080

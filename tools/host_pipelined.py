@@ -1,9 +1,9 @@
 """Pipelined host ingest (vt_group_enqueue_host / vt_group_wait_next) for a rocprofv3 trace:
    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d OUT -- python3 tools/host_pipelined.py 30 1 12
-usage: python tools/host_pipelined.py [streams_per_engine] [engines] [steps] [sync]"""
+usage: python tools/host_pipelined.py [streams_per_engine] [engines] [steps] [sync|pipe] [eager]"""
 import sys, time, threading
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
@@ -14,7 +14,8 @@ w, h, R = 1920, 1080, 16
 wts = vt.weights.ensure_weights("cfg3")
 sc = vt.synth.MovingSquare(w, h, 64, seed=0)
 clip = [vt.NV12Frame(sc.frame_nv12(t), w, h) for t in range(R)]
-groups = [vt.Group(wts, n_streams=B) for _ in range(G)]
+eager = len(sys.argv) > 5 and sys.argv[5] == "eager"
+groups = [vt.Group(wts, n_streams=B, use_graph=not eager) for _ in range(G)]
 for g in groups:
     for i in range(B):
         g.init_host(i, clip[0], vt.BBox.new(*sc.gt_box(0)))
@@ -40,6 +41,6 @@ th = [threading.Thread(target=run, args=(g, steps, oks)) for g in groups]
 [x.start() for x in th]
 [x.join() for x in th]
 dt = time.perf_counter() - t0
-print(f"{'synchronous' if sync else 'pipelined'} host frames, {G} engines x {B} streams: {G * B * steps / dt:.0f} "
+print(f"{'synchronous' if sync else 'pipelined'}{' eager' if eager else ''} host frames, {G} engines x {B} streams: {G * B * steps / dt:.0f} "
       f"tracked frames/s ({dt / steps * 1e3:.2f} ms per step of {G * B} frames), all tracked: {all(oks)}, "
       f"redone passes: {sum(g.host_redos() for g in groups)}")

@@ -3,7 +3,7 @@ engine, 1080p NV12 frames in ordinary host memory; only the search windows are p
 usage: python tools/host_throughput.py [streams_per_engine] [engines] [steps]"""
 import sys, time, threading
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 30

@@ -1,7 +1,7 @@
 """small-M and head GEMM shapes across the 4-wave kernel's configurations (one process)"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 shapes = [(720, 2304, 768, 4, "qkv B=1"), (720, 768, 768, 1, "proj B=1"), (720, 3072, 768, 2, "fc1 B=1"),
           (720, 768, 3072, 1, "fc2 B=1"), (17280, 128, 1152, 3, "head conv B=30"), (17280, 128, 768, 3, "head 1x1 B=30"),

@@ -8,7 +8,7 @@ graph, a step enqueues one pass on every engine and waits for all of them (as be
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))   # repo root
 import gstreamer_vit_tracker_amd as vt
 
 specs = list(sys.argv[1:])
