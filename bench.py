@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--ring", type=int, default=64, help="distinct frames kept in HBM per clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive leg")
-    ap.add_argument("--host-steps", type=int, default=40)
+    ap.add_argument("--host-steps", type=int, default=100)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
     args = ap.parse_args()
