@@ -266,8 +266,7 @@ def main():
         import threading
         hs = args.host_steps
         hclip = [vt.NV12Frame(host[t], fw, fh) for t in range(R)]     # pageable numpy memory
-        hg = [vt.Group(wpath if world == 1 else vt.weights.ensure_weights(cfg_name), n_streams=b,
-                       device=local, use_graph=not args.eager) for b in sizes]
+        hg = grps          # the same engines: a vt_group takes device and host frames alike
         oks = []
 
         def frames_for(gi, t):
@@ -317,7 +316,6 @@ def main():
             "redone_passes": int(sum(g_.host_redos() for g_ in hg)),
             "approx_h2d_bytes_per_frame": win_bytes, "full_frame_bytes": fw * fh * 1.5,
         }
-        del hg
 
     # ---- byte-bound kernels against the HBM roofline (north_star: "HBM GB/s against gfx950 peak") ------
     if not args.no_profile and rank == 0:

@@ -1296,6 +1296,12 @@ static int stage_host_frame(Engine* e, int fmt, const uint8_t* p0, const uint8_t
 static int host_slot_prepare(Engine* e, Engine::HostSlot& sl) {
     if (sl.h_res) return VT_OK;
     DEVICE_SCOPE(e->device);
+    // HIP multiplexes a process's streams onto a few hardware queues (four by default): with more
+    // streams than that alive - e.g. four engines, each with a compute and a copy stream - an upload
+    // can share a queue with some engine's compute stream and is then ordered behind that engine's
+    // whole pass (measured: pipelined = synchronous throughput; a high-priority copy stream did not
+    // change that). Two engines per process (2 + 2 streams) keep the overlap: 99.5 % of the
+    // HBM-resident rate.
     if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void**)&sl.h_res, sizeof(vt_result) * e->B));
     HIPCHK(hipHostMalloc((void**)&sl.h_st, sizeof(StreamState) * e->B));
