@@ -262,7 +262,7 @@ def main():
     # timing that includes the H2D copy, beside the HBM-resident `value` (never
     # instead of it). Only each stream's search window crosses PCIe (~100 KB for a 64-px target; a whole
     # 1080p NV12 frame is 3.11 MB); one host thread per engine, as a host with G capture threads would.
-    if not args.no_host_leg and rank == 0:
+    if not args.no_host_leg and rank == 0 and world == 1:     # like cpu_baseline: at N = 1 only
         import threading
         hs = args.host_steps
         hclip = [vt.NV12Frame(host[t], fw, fh) for t in range(R)]     # pageable numpy memory

@@ -1,2 +1,2 @@
-python bench.py --no-cpu-baseline --no-profile --steps 50 --warmup 10 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['pcie_inclusive']['value'], d['pcie_inclusive']['synchronous_value'], d['pcie_inclusive']['tracked_ok'])"
-python bench.py --no-cpu-baseline --steps 50 --warmup 10 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['pcie_inclusive']['value'], d['pcie_inclusive']['synchronous_value'], d['pcie_inclusive']['tracked_ok'])"
+python tools/gemm_ab.py 0,1,3,17,19 4,8,16 3
+python tools/split_bench.py cfg3 8 4+4 16 8+8 20 10+10
