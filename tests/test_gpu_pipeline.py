@@ -248,6 +248,39 @@ def test_batched_30_streams_cfg3_large_tile_path(gpu, oracle, weights_cfg3):
             assert d <= 1 and abs(res[i].score - r.score) < 0.03, (t, i, res[i], r)
 
 
+def test_planned_engines_run_concurrently_and_track_like_one_engine(gpu, weights_cfg3):
+    """vt_plan_engines splits 33 ViT-B/16 streams into engines of 30 + 3 (no engine just past a GEMM
+    round boundary). Both engines are enqueued before either is waited for, so their kernels share
+    the GPU; every stream must track its square, and agree with the same stream run in ONE engine of
+    33 (different tile kernels, so +-1 px and 0.02 in score rather than bit-equality)."""
+    import torch
+    n, w, h = 33, 1920, 1080
+    sizes = gpu.plan_engines(gpu.Group(weights_cfg3, n_streams=1).model_info(), n)
+    assert sizes == [30, 3] and sizes == gpu.weights.plan_engines("cfg3", n)
+    scs = [gpu.synth.MovingSquare(w, h, 64, seed=300 + i) for i in range(n)]
+    engines = [gpu.Group(weights_cfg3, n_streams=b) for b in sizes]
+    one = gpu.Group(weights_cfg3, n_streams=n)
+    off = [0, sizes[0], n]
+    for t in range(4):
+        bufs = [torch.from_numpy(sc.frame_nv12(t)).cuda() for sc in scs]
+        frames = [gpu.frame_nv12(b.data_ptr(), b.data_ptr() + w * h, w, h) for b in bufs]
+        if t == 0:
+            for i in range(n):
+                e = 0 if i < sizes[0] else 1
+                engines[e].init_device(i - off[e], frames[i], gpu.BBox.new(*scs[i].gt_box(0)))
+                one.init_device(i, frames[i], gpu.BBox.new(*scs[i].gt_box(0)))
+            continue
+        for e in range(2):
+            engines[e].enqueue_device(frames[off[e]:off[e + 1]])
+        res = engines[0].wait() + engines[1].wait()
+        ref = one.update_device(frames)
+        for i in range(n):
+            gx, gy, _, _ = scs[i].gt_box(t)
+            assert res[i].success and abs(res[i].bbox[0] - gx) <= 4 and abs(res[i].bbox[1] - gy) <= 4, (t, i, res[i])
+            d = np.abs(np.array(res[i].bbox) - np.array(ref[i].bbox)).max()
+            assert d <= 1 and abs(res[i].score - ref[i].score) < 0.02, (t, i, res[i], ref[i])
+
+
 def test_group_host_frames_equal_device_frames(gpu, weights_tiny):
     """vt_group_update_host: B host frames of mixed pixel formats in one call (windows packed into
     one pinned arena, one H2D copy) give exactly what the same frames resident in HBM give."""
