@@ -107,6 +107,47 @@ def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
     assert gt_iou.min() > 0.5, "the oracle lost the target: the parity above would be vacuous"
 
 
+def test_closed_loop_cfg3_through_the_batched_large_tile_path(gpu, capsys):
+    """The same 300-frame gate on the path bench.py times: ONE engine of 30 streams (M = 21,600 rows:
+    every encoder GEMM on the 256x256 kernels - persistent for QKV / fc1 -, attention on the LDS-DMA
+    kernel), every stream fed the fixture's clip. The single-tracker test above runs the same weights
+    through the small-tile kernels; here each of the 30 streams must meet the fixture's bars, and -
+    the inputs being identical - all 30 must agree with each other exactly (a kernel whose result
+    depended on the row's position in the batch would show here)."""
+    name = "traj_cfg3_300.npz"
+    fx, bar = _fixture(name), BARS[name]
+    weights = gpu.weights.ensure_weights("cfg3")
+    assert _sha256(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
+    sc = _clip(gpu, fx)
+    w, h, n, B = sc.w, sc.h, int(fx["frames"]), 30
+    grp = gpu.Group(weights, n_streams=B)
+    boxes, scores, succ = [], [], []
+    for t in range(n):
+        f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+        if t == 0:
+            for i in range(B):
+                grp.init_host(i, f, gpu.BBox.new(*sc.gt_box(0)))
+        res = grp.update_host([f] * B)
+        boxes.append([r.bbox for r in res])
+        scores.append([r.score for r in res])
+        succ.append([int(r.success) for r in res])
+    boxes, scores, succ = np.array(boxes), np.array(scores), np.array(succ)      # [n][B][4], [n][B]
+    assert np.array_equal(boxes, np.repeat(boxes[:, :1], B, axis=1)), "streams with identical input disagree"
+    assert np.array_equal(scores, np.repeat(scores[:, :1], B, axis=1))
+    b0 = boxes[:, 0]
+    d = np.abs(b0 - fx["bbox"])
+    ious = np.array([iou(tuple(a), tuple(b)) for a, b in zip(b0, fx["bbox"])])
+    dscore = np.abs(scores[:, 0] - fx["score"])
+    with capsys.disabled():
+        print(f"\n[{name}, 30-stream engine] {n} frames x {B} streams: max |delta| {d.max()} px, IoU(hip, oracle) min "
+              f"{ious.min():.4f} mean {ious.mean():.5f}, identical boxes: {(d.max(axis=1) == 0).sum()}, "
+              f"max |delta score| {dscore.max():.4f}; all {B} streams bit-identical to each other")
+    assert d.max() <= bar["px"], f"max |delta| = {d.max()} px at frame {int(d.max(axis=1).argmax())}"
+    assert ious.mean() >= bar["mean_iou"] and ious.min() >= bar["min_iou"]
+    assert np.array_equal(succ[:, 0], fx["success"].astype(int)), "success flags differ"
+    assert dscore.max() < 0.10
+
+
 def test_teacher_forced_on_the_noisy_first_generation_head(gpu, capsys):
     fx = _fixture("forced_cfg3_300.npz")
     with np.load(os.path.join(GOLD, "head_gen1_cfg3.npz")) as z:
