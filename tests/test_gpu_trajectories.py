@@ -107,19 +107,22 @@ def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
     assert gt_iou.min() > 0.5, "the oracle lost the target: the parity above would be vacuous"
 
 
-def test_closed_loop_cfg3_through_the_batched_large_tile_path(gpu, capsys):
-    """The same 300-frame gate on the path bench.py times: ONE engine of 30 streams (M = 21,600 rows:
-    every encoder GEMM on the 256x256 kernels - persistent for QKV / fc1 -, attention on the LDS-DMA
-    kernel), every stream fed the fixture's clip. The single-tracker test above runs the same weights
-    through the small-tile kernels; here each of the 30 streams must meet the fixture's bars, and -
-    the inputs being identical - all 30 must agree with each other exactly (a kernel whose result
-    depended on the row's position in the batch would show here)."""
-    name = "traj_cfg3_300.npz"
+@pytest.mark.parametrize("name", ["traj_cfg3_300.npz", "traj_cfg2_300.npz", "traj_cfg5_60.npz"])
+def test_closed_loop_through_the_batched_large_tile_path(gpu, name, capsys):
+    """The same full-length gate on the path bench.py times: ONE engine of as many streams as
+    vt_recommended_streams says (cfg3: 30 streams, M = 21,600 rows: every encoder GEMM on the 256x256
+    kernels - persistent for QKV / fc1 -, attention on the LDS-DMA kernel), every stream fed the
+    fixture's clip. The single-tracker test above runs the same weights through the small-tile
+    kernels; here each stream must meet the fixture's bars, and - the inputs being identical - all
+    streams must agree with each other exactly (a kernel whose result depended on the row's position
+    in the batch would show here)."""
     fx, bar = _fixture(name), BARS[name]
-    weights = gpu.weights.ensure_weights("cfg3")
+    cfg = str(fx["config"])
+    weights = gpu.weights.ensure_weights(cfg)
     assert _sha256(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
     sc = _clip(gpu, fx)
-    w, h, n, B = sc.w, sc.h, int(fx["frames"]), 30
+    w, h, n, B = sc.w, sc.h, int(fx["frames"]), gpu.weights.recommended_streams(cfg)
+    assert B >= 30
     grp = gpu.Group(weights, n_streams=B)
     boxes, scores, succ = [], [], []
     for t in range(n):
@@ -139,7 +142,7 @@ def test_closed_loop_cfg3_through_the_batched_large_tile_path(gpu, capsys):
     ious = np.array([iou(tuple(a), tuple(b)) for a, b in zip(b0, fx["bbox"])])
     dscore = np.abs(scores[:, 0] - fx["score"])
     with capsys.disabled():
-        print(f"\n[{name}, 30-stream engine] {n} frames x {B} streams: max |delta| {d.max()} px, IoU(hip, oracle) min "
+        print(f"\n[{name}, {B}-stream engine] {n} frames x {B} streams: max |delta| {d.max()} px, IoU(hip, oracle) min "
               f"{ious.min():.4f} mean {ious.mean():.5f}, identical boxes: {(d.max(axis=1) == 0).sum()}, "
               f"max |delta score| {dscore.max():.4f}; all {B} streams bit-identical to each other")
     assert d.max() <= bar["px"], f"max |delta| = {d.max()} px at frame {int(d.max(axis=1).argmax())}"
