@@ -131,6 +131,37 @@ def test_network_stage_taps(gpu, oracle, cfg):
     g.enable_taps(False)
 
 
+def test_network_stage_taps_on_the_30_stream_engine(gpu, oracle, weights_cfg3):
+    """the same per-block comparison on the benchmark's shapes: one engine of 30 cfg3 streams runs every
+    encoder GEMM on the 256x256 kernels (persistent for QKV / fc1); the first and the last stream's
+    residual streams after every block, features and head logits against one oracle forward"""
+    B = 30
+    sc = gpu.synth.MovingSquare(640, 480, 64, seed=2)
+    buf, box = sc.frame_nv12(0), sc.gt_box(0)
+    grp = gpu.Group(weights_cfg3, n_streams=B)
+    grp.enable_taps(True)
+    f = gpu.NV12Frame(buf, 640, 480)
+    for i in range(B):
+        grp.init_host(i, f, gpu.BBox.new(*box))
+    res = grp.update_host([f] * B)
+    ref = oracle.VitTrackRef(weights_cfg3)
+    of = oracle.Frame.nv12(buf, 640, 480)
+    ref.init(of, box)
+    r_ref = ref.update(of, taps=True)
+    mi = grp.model_info()
+    n, d = mi.tokens_template + mi.tokens_search, mi.dim
+    for i in (0, B - 1):
+        assert np.array_equal(grp.read_tensor("patches", i).reshape(n, mi.kpad),
+                              oracle.bf16_bits_to_f32(ref.last["patches"]))
+        assert _rel(grp.read_tensor("tokens0", i).reshape(n, d), ref.last["tokens0"]) < 1e-5
+        for l in range(mi.layers):
+            assert _rel(grp.read_tensor(f"layer{l}", i).reshape(n, d), ref.last[f"layer{l}"]) < 2e-2, (i, l)
+        assert _rel(grp.read_tensor("feat", i).reshape(mi.tokens_search, d), ref.last["feat"]) < 3e-2
+        ho = grp.read_tensor("head_out", i).reshape(mi.tokens_search, 8)
+        assert np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() < 0.05 * max(1.0, np.abs(ref.last["head_out"]).max())
+        assert abs(res[i].score - r_ref.score) < 0.02 and np.abs(np.array(res[i].bbox) - np.array(r_ref.bbox)).max() <= 1
+
+
 # ---- stage (d): closed-loop trajectories ------------------------------------------------------------
 
 def _run_pair(gpu, oracle, weights, sc, frames, use_nv12=True, use_graph=True):
