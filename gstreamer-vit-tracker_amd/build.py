@@ -98,8 +98,18 @@ def build_host(force: bool = False) -> str:
     return LIB_HOST
 
 
+def build_c_client(force: bool = False) -> str:
+    """harness/c_client: the ABI driven from plain C99 (strict flags: the header must be valid C for a
+    binding generator); loads libvittrack_hip.so with dlopen at run time"""
+    src, out = os.path.join(HOST, "c_client.c"), os.path.join(HOST, "c_client")
+    if force or _newer(out, [src, os.path.join(PKG, "..", "include", "vittrack_hip.h")]):
+        _run(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1",
+              "-o", out, src, "-ldl"])
+    return out
+
+
 def build_all(force: bool = False):
-    return build_hip(force), build_host(force)
+    return build_hip(force), build_host(force), build_c_client(force)
 
 
 if __name__ == "__main__":
@@ -110,3 +120,5 @@ if __name__ == "__main__":
     print(build_hip(force, save_temps="--save-temps" in sys.argv))
     if os.path.exists(os.path.join(HOST, "host_capi.cpp")):
         print(build_host(force))
+    if os.path.exists(os.path.join(HOST, "c_client.c")):
+        print(build_c_client(force))

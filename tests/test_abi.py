@@ -52,3 +52,24 @@ def test_no_gpu_means_loud_failure_not_fallback(vt, weights_tiny):
     assert e.value.code == -2
     with pytest.raises(vt.VtError):
         vt.nv12_full_to_rgb(__import__("numpy").zeros(96, "uint8"), 8, 8)
+
+
+def test_header_is_strict_c99_and_gives_a_c_compiler_the_same_layouts(vt):
+    """harness/c_client.c includes include/vittrack_hip.h from plain C (what bindgen / cgo would
+    consume) and is compiled with -std=c99 -Wall -Wextra -Werror -pedantic by build.py; the struct
+    sizes a C compiler derives from the header must be the ones the ctypes binding uses"""
+    import ctypes
+    import subprocess
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_vt_build", os.path.join(root, "gstreamer-vit-tracker_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    exe = b.build_c_client()
+    out = subprocess.run([exe, "sizes"], capture_output=True, text=True, check=True).stdout.split()
+    got = dict(zip(out[0::2], (int(x) for x in out[1::2])))
+    assert got["vt_config"] == ctypes.sizeof(vt.CConfig)
+    assert got["vt_model_info"] == ctypes.sizeof(vt.CModelInfo)
+    assert got["vt_frame"] == ctypes.sizeof(vt.CFrame)
+    assert got["vt_result"] == ctypes.sizeof(vt.CResult) and got["vt_bbox"] == 16
+    assert got["abi"] == vt.lib().vt_abi_version() and got["max_streams"] == 1024

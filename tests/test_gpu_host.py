@@ -115,3 +115,30 @@ def test_rccl_weight_broadcast_without_python_collectives(gpu, weights_tiny):
                 grp.init_device(0, fr[0], gpu.BBox.new(*sc.gt_box(0)))
         ra, rb = g.update_device(fr)[0], ref.update_device(fr)[0]
         assert ra.bbox == rb.bbox and ra.score == rb.score
+
+
+def test_plain_c_client_tracks_like_the_python_binding(gpu, weights_tiny, tmp_path):
+    """the reference's call sequence (new -> init -> update ...) driven from a C99 program that knows
+    only include/vittrack_hip.h and dlopen: same results as the ctypes binding, to the last bit"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "c_client")
+    assert os.path.exists(exe), "harness/c_client missing: python __graft_entry__.py"
+    w, h, n = 640, 480, 12
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=5)
+    frames = [sc.frame_nv12(t) for t in range(n)]
+    clip = tmp_path / "clip.nv12"
+    clip.write_bytes(b"".join(f.tobytes() for f in frames))
+    box = sc.gt_box(0)
+    out = subprocess.run([exe, "run", gpu.LIB_PATH, weights_tiny, str(clip), str(w), str(h), str(n)] +
+                         [str(int(v)) for v in box], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    trk = gpu.VitTrack.new(weights_tiny)
+    trk.init(gpu.NV12Frame(frames[0], w, h), gpu.BBox.new(*box))
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == n
+    for t, line in enumerate(lines):
+        r = trk.update(gpu.NV12Frame(frames[t], w, h))
+        tt, succ, score, x, y, bw, bh = line.split()
+        assert int(tt) == t and int(succ) == int(r.success) and (int(x), int(y), int(bw), int(bh)) == tuple(r.bbox)
+        assert np.float32(float(score)) == np.float32(r.score)
