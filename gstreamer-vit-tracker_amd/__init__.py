@@ -89,7 +89,7 @@ EXPORTS = [
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
-    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench",
+    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_conv3x3_relu_bf16",
     "vt_rccl_unique_id", "vt_broadcast_weights_rccl", "vt_free_device_blob",
 ]
 
@@ -178,6 +178,7 @@ def lib():
     L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
     L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
+    L.vt_op_conv3x3_relu_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int]
     L.vt_op_nv12_to_rgb8_bench.argtypes = [c_int, c_int, c_int, c_int, fp]
     L.vt_rccl_unique_id.argtypes = [u8p]
     L.vt_broadcast_weights_rccl.argtypes = [u8p, c_int, c_int, c_int, c_char_p, POINTER(c_void_p),
@@ -679,6 +680,19 @@ def op_nv12_to_rgb8_bench(w, h, iters=50, device=0) -> float:
     us = c_float()
     _check(lib().vt_op_nv12_to_rgb8_bench(device, w, h, iters, byref(us)))
     return float(us.value)
+
+
+def op_conv3x3_relu(t_bf16_bits, w_bf16_bits, bias, B, grid, cfg=-1, device=0):
+    """vt_op_conv3x3_relu_bf16: relu(conv3x3(t) + bias) as the implicit GEMM of the head; t [B*grid*grid][C],
+    w [N][9*C] as uint16 bf16 bit patterns -> [B*grid*grid][N] float32 (bf16 values)"""
+    t = np.ascontiguousarray(t_bf16_bits, np.uint16)
+    w = np.ascontiguousarray(w_bf16_bits, np.uint16)
+    C, N = t.shape[1], w.shape[0]
+    out = np.empty((t.shape[0], N), np.float32)
+    _check(lib().vt_op_conv3x3_relu_bf16(device, t.ctypes.data_as(POINTER(ctypes.c_uint16)),
+                                         w.ctypes.data_as(POINTER(ctypes.c_uint16)),
+                                         _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, C, N, cfg))
+    return out
 
 
 def op_layernorm(x, gamma, beta, device=0):

@@ -1,7 +1,7 @@
 // k_gemm.hip — bf16 MFMA GEMM for gfx950: C[M,N] = A[M,K] · W[N,K]^T (+ fused epilogue).
 //
 // Every dense contraction of the tracker goes through this kernel: patch-embed, QKV, attention
-// output projection, MLP fc1/fc2, and the head's 1x1 / im2col'd 3x3 convolutions. Both operands
+// output projection, MLP fc1/fc2, and the head's 1x1 / 3x3 (implicit-GEMM) convolutions. Both operands
 // are K-contiguous ("A rows" and "W rows"), so one staging routine and one fragment reader serve
 // both.
 //
@@ -35,7 +35,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE>
+template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                               f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
     constexpr int BK = GEMM_BK;
@@ -58,6 +58,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     // per-lane source pointers for the LDS-DMA pieces this wave issues (rows fixed over K)
     const bf16_t* asrc[PA];
     const bf16_t* bsrc[PB];
+    // implicit 3x3 convolution: the row's cell in its map and the column chunk this lane fetches
+    int cv_cell[PA], cv_y[PA], cv_x[PA], cv_c[PA];
+    const bool conv = CONV && p.conv_grid > 0;
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int row = (wave * PA + j) * RPP + (lane / CPR);
@@ -65,6 +68,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
         asrc[j] = p.A + (size_t)gm * p.lda + c * 8;
+        if constexpr (CONV) {
+            const int g = p.conv_grid > 0 ? p.conv_grid : 1, cell = gm % (g * g);
+            cv_cell[j] = gm; cv_y[j] = cell / g; cv_x[j] = cell % g; cv_c[j] = c * 8;
+        }
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
@@ -75,8 +82,21 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
     // piece q of a stage: q < PA -> A rows, else W rows (each piece = one global_load_lds, 1 KiB)
     auto issue_piece = [&](int kt, int buf, int q) {
         char* sA = smem + buf * STAGE;
-        if (q < PA) glds16(asrc[q] + kt * BK, sA + (wave * PA + q) * 1024);
-        else glds16(bsrc[q - PA] + kt * BK, sA + BM * ROWB + (wave * PB + (q - PA)) * 1024);
+        if (q < PA) {
+            if (conv) {       // K-tile kt = 64 channels [cc, cc + 64) of tap (ky, kx) of the 3x3 window
+                const int k0 = kt * BK, tap = k0 / p.conv_C, cc = k0 - tap * p.conv_C;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int y = cv_y[q] + ky - 1, x = cv_x[q] + kx - 1;
+                const bool in = y >= 0 && y < p.conv_grid && x >= 0 && x < p.conv_grid;
+                const bf16_t* src = in ? p.A + (size_t)(cv_cell[q] + (ky - 1) * p.conv_grid + (kx - 1)) * p.lda + cc + cv_c[q]
+                                       : p.zeros + cv_c[q];
+                glds16(src, sA + (wave * PA + q) * 1024);
+            } else {
+                glds16(asrc[q] + kt * BK, sA + (wave * PA + q) * 1024);
+            }
+        } else {
+            glds16(bsrc[q - PA] + kt * BK, sA + BM * ROWB + (wave * PB + (q - PA)) * 1024);
+        }
     };
     auto stage = [&](int kt, int buf) {
 #pragma unroll
@@ -266,7 +286,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
-            gemm_mainloop<BM, BN, WVM, WVN, NS, true>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
 #pragma unroll
@@ -491,6 +511,9 @@ static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
 
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st) {
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
+    if (a.conv_grid > 0 && (epilogue != EPI_RELU_BF16 || cfg > 3 || a.conv_C % GEMM_BK != 0 || a.K != 9 * a.conv_C ||
+                            a.lda != a.conv_C || !a.zeros || a.M % (a.conv_grid * a.conv_grid) != 0))
+        return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
         return hipErrorInvalidValue;
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);

@@ -1,4 +1,4 @@
-// k_misc.hip — LayerNorm, head im2col, and the on-device box decode for gfx950.
+// k_misc.hip — LayerNorm, the head's last layer and the on-device box decode for gfx950.
 #include "vt_common.hpp"
 
 // ---- LayerNorm: one wave per row, row kept in registers, two-pass variance -----------------------
@@ -128,40 +128,6 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
         default: return hipErrorInvalidValue;
     }
 #undef LN_CASE
-    return hipGetLastError();
-}
-
-// ---- im2col for the head's 3x3 convolutions (zero padding), 16 B per lane -----------------------
-// t [B*grid*grid][C] -> col [B*grid*grid][9*C], column (ky*3+kx)*C + c
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict__ t,
-                                                        bf16_t* __restrict__ col, int B, int grid,
-                                                        int C) {
-    const int chunks = C / 8;
-    const long total = (long)B * grid * grid * 9 * chunks;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % chunks);
-        long rest = i / chunks;
-        const int tap = (int)(rest % 9);
-        rest /= 9;
-        const int cell = (int)(rest % (grid * grid));
-        const int b = (int)(rest / (grid * grid));
-        const int y = cell / grid + tap / 3 - 1, x = cell % grid + tap % 3 - 1;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (y >= 0 && y < grid && x >= 0 && x < grid)
-            v = *reinterpret_cast<const uint4*>(t + ((size_t)b * grid * grid + y * grid + x) * C +
-                                                ch * 8);
-        *reinterpret_cast<uint4*>(col + ((size_t)b * grid * grid + cell) * 9 * C + tap * C +
-                                  ch * 8) = v;
-    }
-}
-
-hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C, hipStream_t st) {
-    if (C % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)B * grid * grid * 9 * (C / 8);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks), dim3(256), 0, st, t, col, B, grid, C);
     return hipGetLastError();
 }
 

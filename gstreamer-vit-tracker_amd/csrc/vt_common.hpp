@@ -75,6 +75,13 @@ struct GemmArgs {
     bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
     int vt_perm;                  // Vt key order inside each group of 16: 0 natural, 1 attn_perm16 (attention mode 3)
     unsigned long long* dbg;      // diagnostic builds only (VT_STAMPS): per-wave cycle sums
+    // Implicit 3x3 convolution (zero padding) on the head's feature maps, 4-wave kernel with the ReLU
+    // epilogue only: conv_grid > 0 makes A the map t[M = B*grid*grid][conv_C] (lda = conv_C) and the
+    // GEMM's K = 9*conv_C the im2col row (ky*3+kx)*conv_C + c, gathered tap by tap while the LDS-DMA
+    // pieces are issued (a K-tile of 64 lies inside one tap: conv_C % 64 == 0). Out-of-map taps read
+    // `zeros` (>= 128 B of zeros in device memory).
+    int conv_grid, conv_C;
+    const bf16_t* zeros;
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);
@@ -116,7 +123,6 @@ hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* 
 
 hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st);
 
-hipError_t launch_im2col3x3(const bf16_t* t, bf16_t* col, int B, int grid, int C, hipStream_t st);
 
 hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, const vt_draw_cmd* d_cmds,
                           int n, hipStream_t st);

@@ -130,7 +130,7 @@ struct Engine {
     // activations
     bf16_t *d_patches = nullptr, *d_ln = nullptr, *d_qk = nullptr, *d_vt = nullptr,
            *d_attn = nullptr, *d_mlp = nullptr, *d_feat = nullptr, *d_ta = nullptr,
-           *d_tb = nullptr, *d_col = nullptr;
+           *d_tb = nullptr, *d_zeros = nullptr;     // d_zeros: 256 B of zeros (out-of-map taps of the 3x3 convs)
     float *d_x = nullptr, *d_headout = nullptr, *d_taps = nullptr;
     StreamState* d_states = nullptr;
     FrameDesc* d_frames = nullptr;
@@ -203,7 +203,7 @@ void Engine::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    void* devp[] = {d_blob, d_patches, d_ln, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_col,
+    void* devp[] = {d_blob, d_patches, d_ln, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
                     d_x, d_headout, d_taps, d_states, d_frames, d_results, d_stage};
     for (void* p : devp)
         if (p) (void)hipFree(p);
@@ -368,7 +368,7 @@ static hipError_t dalloc0(T** p, size_t count) {
 size_t Engine::activation_bytes() const {
     const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
     return 2 * (M * d.kpad + M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
-                Ms * d.D + 2 * Ms * d.C + Ms * 9 * d.C) +
+                Ms * d.D + 2 * Ms * d.C) +
            4 * (M * d.D + Ms * 8) + (size_t)B * (sizeof(StreamState) + sizeof(FrameDesc) + sizeof(vt_result));
 }
 
@@ -395,7 +395,7 @@ int Engine::alloc_buffers() {
     HIPCHK(dalloc0(&d_feat, Ms * d.D));
     HIPCHK(dalloc0(&d_ta, Ms * d.C));
     HIPCHK(dalloc0(&d_tb, Ms * d.C));
-    HIPCHK(dalloc0(&d_col, Ms * 9 * d.C));
+    HIPCHK(dalloc0(&d_zeros, (size_t)128));
     HIPCHK(dalloc0(&d_headout, Ms * 8));
     HIPCHK(dalloc0(&d_states, (size_t)B));
     {   // B frame descriptors + the pass's PassOut behind them (one upload per pass)
@@ -523,7 +523,7 @@ int Engine::run_pass(Profiler* prof) {
                                 (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
                                 d.nt, d.ln_eps, stream);
     });
-    // centre head: 1x1 conv, three 3x3 convs (im2col + GEMM), then the f32 5-logit layer + decode
+    // centre head: 1x1 conv, three 3x3 convs (implicit GEMMs), then the f32 5-logit layer + decode
     {
         GemmArgs a{};
         a.A = d_feat; a.lda = D; a.W = (const bf16_t*)find("head.w0")->ptr; a.ldw = D;
@@ -533,14 +533,13 @@ int Engine::run_pass(Profiler* prof) {
     }
     bf16_t* cur = d_ta;
     bf16_t* nxt = d_tb;
-    for (int k = 1; k <= 3; ++k) {
-        L("im2col3x3", 0, (double)Ms * d.C * 2 * 10,
-          [&] { return launch_im2col3x3(cur, d_col, B, d.gs, d.C, stream); });
+    for (int k = 1; k <= 3; ++k) {     // 3x3 convs as implicit GEMMs: the im2col row is gathered by the A loads
         GemmArgs a{};
         const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
-        a.A = d_col; a.lda = 9 * d.C; a.W = (const bf16_t*)find(wn)->ptr; a.ldw = 9 * d.C;
+        a.A = cur; a.lda = d.C; a.W = (const bf16_t*)find(wn)->ptr; a.ldw = 9 * d.C;
         a.bias = (const float*)find(bn)->ptr;
         a.M = Ms; a.N = d.C; a.K = 9 * d.C; a.Cb = nxt; a.ldcb = d.C;
+        a.conv_grid = d.gs; a.conv_C = d.C; a.zeros = d_zeros;
         gemm(EPI_RELU_BF16, a);
         std::swap(cur, nxt);
     }
@@ -1848,6 +1847,37 @@ int vt_op_layernorm(int device_id, const float* x, const float* gamma, const flo
     std::vector<bf16_t> tmp((size_t)M * D);
     HIPCHK(hipMemcpy(tmp.data(), dy.p, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(y + i, &u, 4); }
+    return VT_OK;
+} VT_NOTHROW_INT
+
+// The head's 3x3 convolution (zero padding) + bias + ReLU as the engine runs it: an implicit GEMM over
+// t [B*grid*grid][C] (bf16) with w [N][9*C] (bf16, column (ky*3+kx)*C + c); out [B*grid*grid][N] bf16
+// widened to f32. cfg 0..3 (4-wave kernel), < 0: the launcher's choice.
+int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
+                            int B, int grid, int C, int N, int cfg) try {
+    if (!t || !w || !bias || !out || B < 1 || grid < 1 || C % 64 || N % 64 || cfg > 3)
+        return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    HIPCHK(gemm_prepare());
+    const size_t M = (size_t)B * grid * grid;
+    DevBuf dt, dw, db, dout, dz;
+    HIPCHK(dt.alloc(M * C * 2)); HIPCHK(dw.alloc((size_t)N * 9 * C * 2)); HIPCHK(db.alloc((size_t)N * 4));
+    HIPCHK(dout.alloc(M * N * 2)); HIPCHK(dz.alloc(256));
+    HIPCHK(hipMemcpy(dt.p, t, M * C * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw.p, w, (size_t)N * 9 * C * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dz.p, 0, 256));
+    GemmArgs g{};
+    g.A = (const bf16_t*)dt.p; g.lda = C; g.W = (const bf16_t*)dw.p; g.ldw = 9 * C; g.bias = (const float*)db.p;
+    g.M = (int)M; g.N = N; g.K = 9 * C; g.Cb = (bf16_t*)dout.p; g.ldcb = N;
+    g.conv_grid = grid; g.conv_C = C; g.zeros = (const bf16_t*)dz.p;
+    if (cfg < 0) HIPCHK(launch_gemm(g, EPI_RELU_BF16, nullptr));
+    else HIPCHK(launch_gemm_cfg(g, EPI_RELU_BF16, cfg, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<bf16_t> tmp(M * N);
+    HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
     return VT_OK;
 } VT_NOTHROW_INT
 

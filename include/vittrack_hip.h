@@ -362,6 +362,11 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
  * 17 = 256x256 8-wave, <0 = the launcher's own choice. */
 int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
                      float* us_out);
+/* The head's 3x3 convolution (zero padding) + bias + ReLU as the engine runs it - an implicit GEMM whose
+ * A loads gather the im2col row: t [B*grid*grid][C] bf16, w [N][9*C] bf16 (column (ky*3+kx)*C + c),
+ * out [B*grid*grid][N] (bf16 widened to f32). C % 64 == 0, N % 64 == 0; cfg 0..3, < 0: launcher's choice. */
+int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias,
+                            float* out, int B, int grid, int C, int N, int cfg);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
  * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;

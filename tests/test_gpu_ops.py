@@ -340,6 +340,30 @@ def test_layernorm(gpu, M, D):
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-4)
 
 
+@pytest.mark.parametrize("B,grid,C,N,cfg", [(1, 24, 128, 128, 2), (3, 24, 128, 128, 3), (2, 8, 64, 64, 0),
+                                             (30, 24, 128, 128, -1), (1, 28, 128, 128, 1), (5, 5, 64, 128, 2)])
+def test_head_conv3x3_as_implicit_gemm(gpu, B, grid, C, N, cfg):
+    """the head's 3x3 convolutions gather their im2col rows inside the GEMM's A loads (no im2col
+    kernel, no column buffer): exact small integers against a direct NumPy convolution with zero
+    padding, every tile configuration of the 4-wave kernel, maps that do not fill the last row tile"""
+    rng = np.random.default_rng(B * 1000 + grid * 10 + C + N)
+    t = rng.integers(-3, 4, size=(B, grid, grid, C)).astype(np.float32)
+    w = rng.integers(-2, 3, size=(N, 3, 3, C)).astype(np.float32)
+    bias = rng.integers(-4, 5, size=N).astype(np.float32)
+    pad = np.zeros((B, grid + 2, grid + 2, C), np.float32)
+    pad[:, 1:-1, 1:-1] = t
+    ref = np.zeros((B, grid, grid, N), np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            ref += pad[:, ky:ky + grid, kx:kx + grid].reshape(-1, C).astype(np.float64).dot(
+                w[:, ky, kx].T.astype(np.float64)).reshape(B, grid, grid, N)
+    ref = np.maximum(ref + bias, 0).reshape(-1, N)
+    got = gpu.op_conv3x3_relu(gpu.weights.f32_to_bf16_bits(t.reshape(-1, C)),
+                              gpu.weights.f32_to_bf16_bits(w.reshape(N, 9 * C)), bias, B, grid, cfg=cfg)
+    expect = gpu.weights.bf16_bits_to_f32(gpu.weights.f32_to_bf16_bits(ref.astype(np.float32)))
+    assert np.array_equal(got, expect)
+
+
 @pytest.mark.parametrize("tokens,B", [(720, 30), (980, 9), (100, 70)])
 def test_gemm256_persistent_qkv_and_activation_full_chip(gpu, tokens, B):
     """config 19 (persistent workgroups, wave-private epilogue, next tile's prologue in flight under
