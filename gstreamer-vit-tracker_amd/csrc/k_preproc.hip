@@ -303,6 +303,117 @@ __global__ __launch_bounds__(256) void preproc_wide_kernel(const FrameDesc* __re
     }
 }
 
+// Tile variant (size % 64 == 0, patch % 8 == 0): a block produces a 64 x 32 tile of output pixels.
+// At the usual scales (0.67 source pixels per output pixel for a 64-px target, 1.6 at 4K) the four
+// bilinear taps of neighbouring outputs hit the same few source pixels: the wide kernel fetched and
+// converted every source pixel ~8 times (three 1-byte loads + the integer YUV->RGB each time - the
+// stage was bound by those scattered byte loads, 46 us for 30 streams). Here the tile's source
+// rectangle is fetched ONCE through the same fetch_rgb (formats, frame border, window extent all as
+// before), kept in LDS as r | g << 8 | b << 16 | miss << 24, and the lanes interpolate from LDS. A
+// tap that lay outside the stored window still raises window_miss only if an output pixel uses it.
+// Same arithmetic, same order: bit-exact with the other kernels and the oracle. Rectangles that do
+// not fit the 32 KiB buffer (very large targets) take the direct fetches of the wide kernel.
+#define PRE_TILE_W 64
+#define PRE_TILE_H 32
+#define PRE_TILE_LDS 8192       // source pixels (32 KiB)
+__global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __restrict__ frames,
+                                                           StreamState* __restrict__ states,
+                                                           bf16_t* __restrict__ patches, int b0,
+                                                           int size, int patch, int kpad, int ntok,
+                                                           int row_off, float factor, float na0,
+                                                           float na1, float na2, float nb0, float nb1,
+                                                           float nb2, int is_template) {
+    __shared__ uint32_t src[PRE_TILE_LDS];
+    constexpr int PX = 8;
+    const int b = b0 + blockIdx.y;
+    const FrameDesc f = frames[b];
+    StreamState& s = states[b];
+    // crop geometry — same operations, same order as vto_crop_geometry (oracle/vt_oracle.c)
+    const float bx = s.box[0], by = s.box[1], bw = s.box[2], bh = s.box[3];
+    const float area = bw * bh;
+    const float side = factor * sqrtf(area);
+    const float scale = side / (float)size;
+    const float cx = bx + 0.5f * bw;
+    const float cy = by + 0.5f * bh;
+    const float half = 0.5f * side;
+    const float x0m = (cx - half) - 0.5f;
+    const float y0m = (cy - half) - 0.5f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !is_template) {
+        s.geo[0] = x0m; s.geo[1] = y0m; s.geo[2] = scale; s.geo[3] = side;
+        s.frame_w = f.w; s.frame_h = f.h;
+    }
+    const int tiles_x = size / PRE_TILE_W;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int oy = ty * PRE_TILE_H + (threadIdx.x >> 3), ox0 = tx * PRE_TILE_W + (threadIdx.x & 7) * PX;
+    // source rectangle of the tile: taps of its first and last output pixel (fx, fy grow with ox, oy)
+    const int sx_lo = (int)floorf(((float)(tx * PRE_TILE_W) + 0.5f) * scale + x0m);
+    const int sx_hi = (int)floorf(((float)(tx * PRE_TILE_W + PRE_TILE_W - 1) + 0.5f) * scale + x0m) + 1;
+    const int sy_lo = (int)floorf(((float)(ty * PRE_TILE_H) + 0.5f) * scale + y0m);
+    const int sy_hi = (int)floorf(((float)(ty * PRE_TILE_H + PRE_TILE_H - 1) + 0.5f) * scale + y0m) + 1;
+    const long sw = (long)sx_hi - sx_lo + 1, sh = (long)sy_hi - sy_lo + 1;
+    const bool staged = sw > 0 && sh > 0 && sw * sh <= PRE_TILE_LDS;      // block-uniform
+    if (staged) {
+        const int n = (int)(sw * sh), w_ = (int)sw;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float p[3];
+            int miss = 0;
+            fetch_rgb(f, sx_lo + i % w_, sy_lo + i / w_, p, miss);
+            src[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)miss << 24);
+        }
+        __syncthreads();
+    }
+    const float fy = ((float)oy + 0.5f) * scale + y0m;
+    const float fy0 = floorf(fy);
+    const float wy = fy - fy0;
+    const int iy = (int)fy0;
+    const float na[3] = {na0, na1, na2}, nb[3] = {nb0, nb1, nb2};
+    bf16_t o[3][PX];
+    int miss = 0;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const float fx = ((float)(ox0 + k) + 0.5f) * scale + x0m;
+        const float fx0 = floorf(fx);
+        const float wx = fx - fx0;
+        const int ix = (int)fx0;
+        float p00[3], p01[3], p10[3], p11[3];
+        if (staged) {
+            const int w_ = (int)sw;
+            const uint32_t* r0 = src + (iy - sy_lo) * w_ + (ix - sx_lo);
+            const uint32_t t00 = r0[0], t01 = r0[1], t10 = r0[w_], t11 = r0[w_ + 1];
+            miss |= (int)((t00 | t01 | t10 | t11) >> 24);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p00[c] = (float)((t00 >> (8 * c)) & 255u); p01[c] = (float)((t01 >> (8 * c)) & 255u);
+                p10[c] = (float)((t10 >> (8 * c)) & 255u); p11[c] = (float)((t11 >> (8 * c)) & 255u);
+            }
+        } else {
+            fetch_rgb(f, ix, iy, p00, miss);
+            fetch_rgb(f, ix + 1, iy, p01, miss);
+            fetch_rgb(f, ix, iy + 1, p10, miss);
+            fetch_rgb(f, ix + 1, iy + 1, p11, miss);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = p00[c] + wx * (p01[c] - p00[c]);
+            const float bot = p10[c] + wx * (p11[c] - p10[c]);
+            const float v = top + wy * (bot - top);
+            o[c][k] = f32_to_bf16(v * na[c] + nb[c]);
+        }
+    }
+    if (miss && !is_template) s.window_miss = s.frames_done + 1;   // every writer stores the same value
+    const int grid = size / patch;
+    const int token = (oy / patch) * grid + (ox0 / patch);         // PX divides patch: one token per group
+    const int kin = (oy % patch) * patch + (ox0 % patch);
+    bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint4 v;
+        v.x = o[c][0] | ((uint32_t)o[c][1] << 16); v.y = o[c][2] | ((uint32_t)o[c][3] << 16);
+        v.z = o[c][4] | ((uint32_t)o[c][5] << 16); v.w = o[c][6] | ((uint32_t)o[c][7] << 16);
+        *reinterpret_cast<uint4*>(row + c * patch * patch + kin) = v;
+    }
+}
+
 hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
                           const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st) {
     const int size = is_template ? d.T : d.S;
@@ -311,7 +422,10 @@ hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* 
 #define PRE_ARGS frames, states, patches, b0, size, d.patch, d.kpad, d.ntok, row_off, factor, d.norm_a[0], \
                  d.norm_a[1], d.norm_a[2], d.norm_b[0], d.norm_b[1], d.norm_b[2], is_template ? 1 : 0
     // store alignment: a run starts at element c*p*p + py*p + px0 of a row of kpad elements
-    if (d.patch % 8 == 0 && d.kpad % 8 == 0) {                 // 16-B stores
+    if (d.patch % 8 == 0 && d.kpad % 8 == 0 && size % PRE_TILE_W == 0 && size % PRE_TILE_H == 0) {
+        dim3 grid((size / PRE_TILE_W) * (size / PRE_TILE_H), nb);   // 64 x 32 output tiles, source staged in LDS
+        hipLaunchKernelGGL(preproc_tile_kernel, grid, dim3(256), 0, st, PRE_ARGS);
+    } else if (d.patch % 8 == 0 && d.kpad % 8 == 0) {          // 16-B stores
         dim3 grid((size * size / 8 + 255) / 256, nb);
         hipLaunchKernelGGL(preproc_wide_kernel<8>, grid, dim3(256), 0, st, PRE_ARGS);
     } else if (d.patch % 2 == 0 && d.kpad % 2 == 0) {          // 4-B stores (patch 14)
