@@ -478,13 +478,21 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
         (void)rounds;
         if (t >= 128) return GEMM_CFG_256PP;
     }
+    // Below that the 4-wave kernel (round-2 sweep at 1-8 streams, profiles/r02_small_batch_gemm_ab.txt):
+    // up to 128 tiles of 128x128 the 64x64 tile with the deepest ring wins (most workgroups, three
+    // K-tiles in flight); up to 256 every 128x128 tile has a CU to itself and the ring of 3 (96 KB, one
+    // workgroup per CU) beats the ring of 2; beyond, two workgroups per CU need the ring of 2.
     switch (epilogue) {
         case EPI_QKV:
-        case EPI_GELU_BF16: return (n128 && tiles128 >= 400) ? 3 : 2;
-        case EPI_RELU_BF16: return (n128 && tiles128 >= 256) ? 3 : 2;   // head convs: N = 256
+        case EPI_GELU_BF16:
+            if (!n128) return 2;
+            return tiles128 <= 128 ? 0 : (tiles128 <= 256 ? 1 : 3);
+        case EPI_RELU_BF16: return (n128 && tiles128 >= 256) ? 3 : 2;   // head convs: N = 128
         case EPI_RESID:
-            if (K >= 2048 && M <= 2048) return 0;
-            if (K >= 2048 && n128 && tiles128 >= 256) return 3;
+            if (K >= 2048) {                       // fc2: long dependent K loop
+                if (M <= 2304) return 0;
+                if (n128) return tiles128 < 256 ? 1 : 3;
+            }
             return 2;
         default: return 2;
     }
