@@ -493,7 +493,7 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
                 if (M <= 2304) return 0;
                 if (n128) return tiles128 < 256 ? 1 : 3;
             }
-            return 2;
+            return (n128 && tiles128 >= 256) ? 3 : 2;     // proj: 8-14 streams (beyond, the 256x256 kernel)
         default: return 2;
     }
 }
