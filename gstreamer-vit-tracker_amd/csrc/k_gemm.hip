@@ -28,29 +28,30 @@
 #define ROW_BYTES 128
 
 // LDS ring: NS stages of (BM + BN) rows x 128 B (K-tile depth 64)
-__host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn) { return ns * (bm + bn) * GEMM_BK * 2; }
+__host__ __device__ constexpr int ring_bytes(int ns, int bm, int bn, int bk = GEMM_BK) { return ns * (bm + bn) * bk * 2; }
 
 // accumulator element `reg` of a 32x32 MFMA tile: row offset inside the tile
 __device__ __forceinline__ int acc_row(int reg, int half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, bool ROW_ON_LANE, bool CONV = false>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, bool ROW_ON_LANE, bool CONV = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
                                               f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
-    constexpr int BK = GEMM_BK;
-    constexpr int ROWB = BK * 2;                // bytes per LDS row
-    constexpr int CPR = BK / 8;                 // 16-B chunks per row (8 or 4)
-    constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB LDS-DMA piece (8 or 16)
+    static_assert(BK == 64 || BK == 128, "K-tile depth");
+    constexpr int ROWB = BK * 2;                // bytes per LDS row (128 or 256)
+    constexpr int CPR = BK / 8;                 // 16-B chunks per row (8 or 16)
+    constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB LDS-DMA piece (8 or 4)
     constexpr int NW = WVM * WVN;               // waves per block
     constexpr int WM = BM / WVM, WN = BN / WVN; // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave in each direction
     constexpr int PA = BM / (RPP * NW), PB = BN / (RPP * NW);  // 1-KiB LDS-DMA pieces per wave
     static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
     constexpr int STAGE = (BM + BN) * ROWB;
-    // chunk swizzle c ^ ((r >> 1) & 7): the ds_read_b128 of a 32-row MFMA operand hits 16 distinct
-    // 16-B slots per lane group
-    auto swz = [](int row) { return (row >> 1) & 7; };
+    // chunk swizzle: the ds_read_b128 of a 32-row MFMA operand must hit 16 distinct 16-B slots (one
+    // 256-B bank line) per 16-lane group. 128-B rows (BK 64): two rows share a line, c ^ ((r >> 1) & 7);
+    // 256-B rows (BK 128): one row per line, c ^ (r & 15)
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : row & 15; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WVN, wc = wave % WVN;
     const int l31 = lane & 31, half = lane >> 5;
@@ -211,7 +212,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
 #endif
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
 __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         // assembled in LDS (the operand ring is dead by now) and written out as whole 16-B pieces
         // of contiguous rows.
         constexpr int NT = WVM * WVN * 64;
-        constexpr bool FITS = BM * (BN * 2 + 16) <= ring_bytes(NS, BM, BN) &&
-                              BN * (BM * 2 + 16) <= ring_bytes(NS, BM, BN);
+        constexpr bool FITS = BM * (BN * 2 + 16) <= ring_bytes(NS, BM, BN, BK) &&
+                              BN * (BM * 2 + 16) <= ring_bytes(NS, BM, BN, BK);
         bool v_tile = false;        // QKV: this column tile holds V (stored transposed)
         float scale = 1.0f;
         if constexpr (EPI == EPI_QKV) {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
-            gemm_mainloop<BM, BN, WVM, WVN, NS, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t] with t contiguous (npad per row). MFMA with the
             // column (d) on the lane, 4 consecutive tokens per register quad.
-            gemm_mainloop<BM, BN, WVM, WVN, NS, false>(p, smem, m0, n0, acc);
+            gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BM * 2 + 16;
             const int heads = p.D >> 6;
             if constexpr (FITS) __syncthreads();
@@ -404,35 +405,41 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     }
 }
 
-// Tile configurations {BM, BN, waves M x N, ring depth} of this file's kernel:
-//   0: 64x64   2x2 ring 4    small M, long K (fc2 of one or two streams)
-//   1: 128x128 2x2 ring 3
-//   2: 64x64   2x2 ring 2    small M: most blocks per CU
-//   3: 128x128 2x2 ring 2
+// Tile configurations {BM, BN, waves M x N, ring depth, K-tile depth} of this file's kernel:
+//   0: 64x64   2x2 ring 4 k64    small M, long K (fc2 of two or three streams)
+//   1: 128x128 2x2 ring 3 k64
+//   2: 64x64   2x2 ring 2 k64    small M: most blocks per CU
+//   3: 128x128 2x2 ring 2 k64
+//   4: 64x64   2x2 ring 3 k128   one stream: proj, fc2 (half the iterations of the dependent K loop)
+//   5: 64x64   2x2 ring 2 k128   one stream: QKV; two or three streams: proj
+//   6: 128x128 2x2 ring 2 k128   (measured, never the best: kept for the sweeps)
 // 17 is the 256x256 8-wave kernel of k_gemm256.hip. Numbers 4-16 were experiments on this kernel
 // (256-wide tiles with the same loop, 8-wave blocks, deeper rings, K-tile depth 32, register
 // staging) that never beat 128x128 ring 2 and were removed after the sweep kept in
 // profiles/gemm_sweep_r01.txt.
 #define GEMM_FOR_EACH_CFG(X, EPI) \
-    X(0, 64, 64, 2, 2, 4, EPI)    \
-    X(1, 128, 128, 2, 2, 3, EPI)  \
-    X(2, 64, 64, 2, 2, 2, EPI)    \
-    X(3, 128, 128, 2, 2, 2, EPI)
-#define GEMM_NUM_CFG 20   // valid: 0..3 (this file) and 17, 18, 19 (k_gemm256.hip)
+    X(0, 64, 64, 2, 2, 4, 64, EPI)    \
+    X(1, 128, 128, 2, 2, 3, 64, EPI)  \
+    X(2, 64, 64, 2, 2, 2, 64, EPI)    \
+    X(3, 128, 128, 2, 2, 2, 64, EPI)  \
+    X(4, 64, 64, 2, 2, 3, 128, EPI)   \
+    X(5, 64, 64, 2, 2, 2, 128, EPI)   \
+    X(6, 128, 128, 2, 2, 2, 128, EPI)
+#define GEMM_NUM_CFG 20   // valid: 0..6 (this file) and 17, 18, 19 (k_gemm256.hip)
 
-template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
 static hipError_t prepare_cfg() {
-    constexpr int smem = ring_bytes(NS, BM, BN);
+    constexpr int smem = ring_bytes(NS, BM, BN, BK);
     return hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>),
+        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 template <int EPI>
 static hipError_t prepare_epi() {
     hipError_t e = hipSuccess;
-#define X(id, BM, BN, WVM, WVN, NS, E) \
-    if (e == hipSuccess) e = prepare_cfg<BM, BN, WVM, WVN, NS, E>();
+#define X(id, BM, BN, WVM, WVN, NS, BK, E) \
+    if (e == hipSuccess) e = prepare_cfg<BM, BN, WVM, WVN, NS, BK, E>();
     GEMM_FOR_EACH_CFG(X, EPI)
 #undef X
     return e;
@@ -450,13 +457,14 @@ hipError_t gemm_prepare() {
     return gemm256_prepare();
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = ring_bytes(NS, BM, BN);
-    if (a.N % BN != 0) return hipErrorInvalidValue;
+    constexpr int smem = ring_bytes(NS, BM, BN, BK);
+    if (a.N % BN != 0 || a.K % BK != 0) return hipErrorInvalidValue;
+    if (a.conv_grid > 0 && a.conv_C % BK != 0) return hipErrorInvalidValue;   // a K-tile lies inside one tap
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, EPI>), dim3(tiles),
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI>), dim3(tiles),
                        dim3(WVM * WVN * 64), smem, st, a);
     return hipGetLastError();
 }
@@ -482,35 +490,44 @@ int gemm_pick_config(int M, int N, int K, int epilogue) {
     // up to 128 tiles of 128x128 the 64x64 tile with the deepest ring wins (most workgroups, three
     // K-tiles in flight); up to 256 every 128x128 tile has a CU to itself and the ring of 3 (96 KB, one
     // workgroup per CU) beats the ring of 2; beyond, two workgroups per CU need the ring of 2.
+    // One or two streams are launch- and latency-bound (a K = 768 GEMM of 60 workgroups still takes 7 us):
+    // there a K-tile depth of 128 (configs 4, 5: half the barriers and waits of the dependent K loop)
+    // is worth 0.5 us on the K = 768 shapes and 2-3 us on fc2.
+    const bool k128 = (K % 128) == 0;
     switch (epilogue) {
         case EPI_QKV:
+            if (!n128) return 2;
+            return tiles128 <= 128 ? (k128 ? 5 : 0) : (tiles128 <= 256 ? 1 : 3);
         case EPI_GELU_BF16:
             if (!n128) return 2;
             return tiles128 <= 128 ? 0 : (tiles128 <= 256 ? 1 : 3);
         case EPI_RELU_BF16: return (n128 && tiles128 >= 256) ? 3 : 2;   // head convs: N = 128
         case EPI_RESID:
             if (K >= 2048) {                       // fc2: long dependent K loop
+                if (M <= 1024 && k128) return 4;
                 if (M <= 2304) return 0;
                 if (n128) return tiles128 < 256 ? 1 : 3;
             }
+            if (k128 && M <= 1024) return 4;       // proj, one stream
+            if (k128 && M <= 2304) return 5;
             return (n128 && tiles128 >= 256) ? 3 : 2;     // proj: 8-14 streams (beyond, the 256x256 kernel)
         default: return 2;
     }
 }
 
 const char* gemm_config_name(int cfg) {
-    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2"};
+    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "64x64x3k128", "64x64x2k128", "128x128x2k128"};
     if (cfg == GEMM_CFG_256P8) return "256x256p8";
     if (cfg == GEMM_CFG_256P4) return "256x256p4";
     if (cfg == GEMM_CFG_256PP) return "256x256pp";
-    return (cfg >= 0 && cfg < 4) ? n[cfg] : "?";
+    return (cfg >= 0 && cfg < 7) ? n[cfg] : "?";
 }
 
 template <int EPI>
 static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
-#define X(id, BM, BN, WVM, WVN, NS, E) \
-    case id: return launch_cfg<BM, BN, WVM, WVN, NS, E>(a, st);
+#define X(id, BM, BN, WVM, WVN, NS, BK, E) \
+    case id: return launch_cfg<BM, BN, WVM, WVN, NS, BK, E>(a, st);
         GEMM_FOR_EACH_CFG(X, EPI)
 #undef X
         default: return hipErrorInvalidValue;
@@ -519,7 +536,7 @@ static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
 
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st) {
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
-    if (a.conv_grid > 0 && (epilogue != EPI_RELU_BF16 || cfg > 3 || a.conv_C % GEMM_BK != 0 || a.K != 9 * a.conv_C ||
+    if (a.conv_grid > 0 && (epilogue != EPI_RELU_BF16 || cfg > 6 || a.conv_C % GEMM_BK != 0 || a.K != 9 * a.conv_C ||
                             a.lda != a.conv_C || !a.zeros || a.M % (a.conv_grid * a.conv_grid) != 0))
         return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))

@@ -1855,7 +1855,7 @@ int vt_op_layernorm(int device_id, const float* x, const float* gamma, const flo
 // widened to f32. cfg 0..3 (4-wave kernel), < 0: the launcher's choice.
 int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
                             int B, int grid, int C, int N, int cfg) try {
-    if (!t || !w || !bias || !out || B < 1 || grid < 1 || C % 64 || N % 64 || cfg > 3)
+    if (!t || !w || !bias || !out || B < 1 || grid < 1 || C % 64 || N % 64 || cfg > 6)
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);

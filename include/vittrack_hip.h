@@ -358,13 +358,14 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
                     float* c_inout, int M, int N, int K, int epilogue, int cfg);
 /* Kernel-tuning helper: mean microseconds per launch of the GEMM kernel on device-resident random
  * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
- * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2,
- * 17 = 256x256 8-wave, <0 = the launcher's own choice. */
+ * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2
+ * (K-tile depth 64); 4 = 64x64 ring 3, 5 = 64x64 ring 2, 6 = 128x128 ring 2 (K-tile depth 128, K % 128 == 0);
+ * 17 / 18 / 19 = 256x256 8-wave kernels; <0 = the launcher's own choice. */
 int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
                      float* us_out);
 /* The head's 3x3 convolution (zero padding) + bias + ReLU as the engine runs it - an implicit GEMM whose
  * A loads gather the im2col row: t [B*grid*grid][C] bf16, w [N][9*C] bf16 (column (ky*3+kx)*C + c),
- * out [B*grid*grid][N] (bf16 widened to f32). C % 64 == 0, N % 64 == 0; cfg 0..3, < 0: launcher's choice. */
+ * out [B*grid*grid][N] (bf16 widened to f32). C % 64 == 0, N % 64 == 0; cfg 0..6 (4..6: C % 128 == 0), < 0: launcher's choice. */
 int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias,
                             float* out, int B, int grid, int C, int N, int cfg);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->

@@ -34,13 +34,13 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, cfg, epi):
-    """each tile configuration (64x64 / 128x128 with ring 2..4, and the 256x256 8-wave kernel) on a
-    ragged M, against float32 NumPy"""
+    """each tile configuration (64x64 / 128x128 with ring 2..4 and K-tile depth 64, 4-6: depth 128,
+    and the 256x256 8-wave kernel) on a ragged M, against float32 NumPy"""
     rng = np.random.default_rng(cfg * 10 + epi)
-    M, N, K = 720 + 37, 768, 384
+    M, N, K = 720 + 37, 768, (512 if cfg in (4, 5, 6) else 384)      # K-tile depth 128 there
     ab, a = _rand_bf16(gpu, rng, (M, K))
     wb, w = _rand_bf16(gpu, rng, (N, K), 0.05)
     bias = rng.standard_normal(N).astype(np.float32)
@@ -56,7 +56,7 @@ def test_gemm_every_tile_config(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
 def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)
     B, tokens, D = 2, 100, 768
@@ -82,6 +82,26 @@ def test_gemm_exact_integers_asymmetric(gpu):
     ref = a @ w.T
     got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), None, epilogue=0)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (720, 768, 3072), (131, 128, 256), (1000, 768, 1024)])
+def test_gemm_4wave_exact_integers(gpu, M, N, K, cfg):
+    """the 4-wave kernel's tile configurations (K-tile depth 64 and 128: different LDS row length,
+    swizzle and pieces per stage) on small-integer operands - every product and sum exact, so a
+    mis-staged piece or swizzle slip is a wrong integer; K = 128 is one K-tile of the deep
+    configurations (prologue only), K = 256 two"""
+    rng = np.random.default_rng(M + N + K + cfg)
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
+    ref = a @ w.T + bias
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0, cfg=cfg), ref)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1,
+                                           cfg=cfg), ref + c0)
+    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3, cfg=cfg)
+    assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
 @pytest.mark.parametrize("cfg", [17, 18])
@@ -285,7 +305,7 @@ def test_attention_uniformly_offset_scores(gpu, mode, level):
     assert np.abs(got - ref).max() < 0.02 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 6, 17, 18, 19])
 @pytest.mark.parametrize("tokens", [112, 100])
 def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     """Vt as attention mode 3 reads it: inside every group of 16 tokens OF A STREAM the 4-token runs
@@ -340,7 +360,7 @@ def test_layernorm(gpu, M, D):
     assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-4)
 
 
-@pytest.mark.parametrize("B,grid,C,N,cfg", [(1, 24, 128, 128, 2), (3, 24, 128, 128, 3), (2, 8, 64, 64, 0),
+@pytest.mark.parametrize("B,grid,C,N,cfg", [(1, 24, 128, 128, 2), (3, 24, 128, 128, 3), (2, 8, 64, 64, 0), (2, 24, 128, 128, 4),
                                              (30, 24, 128, 128, -1), (1, 28, 128, 128, 1), (5, 5, 64, 128, 2)])
 def test_head_conv3x3_as_implicit_gemm(gpu, B, grid, C, N, cfg):
     """the head's 3x3 convolutions gather their im2col rows inside the GEMM's A loads (no im2col
