@@ -55,6 +55,14 @@ def usable_cores() -> int:
     return n
 
 
+def baseline_metric() -> str:
+    """BASELINE.json's metric string, verbatim (it travels with the repository snapshot)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "tracked frames/sec @1080p ViT-B/16 384\u00d7192, 1 GPU; + MFMA roofline %"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +210,7 @@ def main():
     ref_fps_stream = 1e6 / (sum(iv) / len(iv)) if sum(iv) else 0.0
 
     out = {
-        "metric": "tracked frames/sec @1080p ViT-B/16 384x192, 1 GPU; + MFMA roofline %",
+        "metric": baseline_metric(),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
