@@ -18,10 +18,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float2 v[NCH];
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        v[j] = xr[lane + 64 * j];
-        sum += v[j].x + v[j].y;
-    }
+    for (int j = 0; j < NCH; ++j) v[j] = xr[lane + 64 * j];
+    const float2* g2 = reinterpret_cast<const float2*>(gamma);     // with the row, not after the reductions
+    const float2* b2 = reinterpret_cast<const float2*>(beta);
+    float2 gq[NCH], bq[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { gq[j] = g2[lane + 64 * j]; bq[j] = b2[lane + 64 * j]; }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)      // keep the loads up here (hipcc sinks them behind the reductions)
+        asm volatile("" : "+v"(gq[j].x), "+v"(gq[j].y), "+v"(bq[j].x), "+v"(bq[j].y) : : "memory");
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) sum += v[j].x + v[j].y;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)D;
@@ -34,12 +41,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
-    const float2* g2 = reinterpret_cast<const float2*>(gamma);
-    const float2* b2 = reinterpret_cast<const float2*>(beta);
     uint32_t* yr = reinterpret_cast<uint32_t*>(y + (size_t)r * D);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        const float2 g = g2[lane + 64 * j], b = b2[lane + 64 * j];
+        const float2 g = gq[j], b = bq[j];
         yr[lane + 64 * j] = pack_bf16x2((v[j].x * rstd) * g.x + b.x, (v[j].y * rstd) * g.y + b.y);
     }
 }
@@ -67,9 +72,26 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
     for (int j = 0; j < NCH; ++j) {
         v[j][0] = xr[2 * (l32 + 32 * j)];
         v[j][1] = xr[2 * (l32 + 32 * j) + 1];
+    }
+    // gamma / beta do not depend on the row: fetched together with it, not after the two reductions
+    // (one dependent memory round trip less - what a launch of a few hundred rows is made of)
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
+    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
+    f32x4_t gq[NCH][2], bq[NCH][2];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = l32 + 32 * j;
+        gq[j][0] = g4[2 * c]; gq[j][1] = g4[2 * c + 1];
+        bq[j][0] = b4[2 * c]; bq[j][1] = b4[2 * c + 1];
+    }
+    // hipcc otherwise sinks these loads back behind the reductions: pin the values here, all loads issued
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        asm volatile("" : "+v"(gq[j][0]), "+v"(gq[j][1]), "+v"(bq[j][0]), "+v"(bq[j][1]) : : "memory");
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum += v[j][0][e] + v[j][1][e];
-    }
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)D;
@@ -86,13 +108,11 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
-    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
-    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
     uint4* yr = reinterpret_cast<uint4*>(y + (size_t)r * D);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = l32 + 32 * j;
-        const f32x4_t g0 = g4[2 * c], g1 = g4[2 * c + 1], b0 = b4[2 * c], b1 = b4[2 * c + 1];
+        const f32x4_t g0 = gq[j][0], g1 = gq[j][1], b0 = bq[j][0], b1 = bq[j][1];
         uint4 o;
         o.x = pack_bf16x2((v[j][0][0] * rstd) * g0[0] + b0[0], (v[j][0][1] * rstd) * g0[1] + b0[1]);
         o.y = pack_bf16x2((v[j][0][2] * rstd) * g0[2] + b0[2], (v[j][0][3] * rstd) * g0[3] + b0[3]);
