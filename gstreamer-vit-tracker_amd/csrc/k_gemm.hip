@@ -241,7 +241,42 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
+        // 64x64 tiles (small batches: a one-stream GEMM is ~8 us of mostly dependent latencies): the
+        // epilogue's addends (old residual / positional rows) and the bias do not depend on the product,
+        // so they are fetched BEFORE the main loop and their latency runs under it instead of being a
+        // round trip at the end of the kernel. Inline-asm global loads: plain loads are sunk to their use
+        // behind the loop by hipcc, volatile ones are each followed by vmcnt(0). Being the oldest entries
+        // of the in-order vector-memory queue they are retired by the loop's first counted wait; the
+        // registers are not touched until the vmcnt(0) below. Rows are clamped: every address is valid.
+        constexpr bool EARLY = TM * TN == 1 && (EPI == EPI_F32_POS || EPI == EPI_RESID);
+        float e_bias = 0.0f, e_add[16];
+        if constexpr (EARLY) {
+            const int n = n0 + wc * WN + l31;
+            if (p.bias) e_bias = gload_f32_asm(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM + acc_row(r, half);
+                const int mc = m < p.M ? m : p.M - 1;
+                e_add[r] = gload_f32_asm(EPI == EPI_F32_POS ? p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n
+                                                            : p.Cf + (size_t)mc * p.ldc + n);
+            }
+        }
         gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
+        if constexpr (EARLY) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(e_bias), "+v"(e_add[0]), "+v"(e_add[1]), "+v"(e_add[2]), "+v"(e_add[3]), "+v"(e_add[4]),
+                           "+v"(e_add[5]), "+v"(e_add[6]), "+v"(e_add[7]), "+v"(e_add[8]), "+v"(e_add[9]), "+v"(e_add[10]),
+                           "+v"(e_add[11]), "+v"(e_add[12]), "+v"(e_add[13]), "+v"(e_add[14]), "+v"(e_add[15])
+                         :
+                         : "memory");
+            const int n = n0 + wc * WN + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM + acc_row(r, half);
+                if (m < p.M) p.Cf[(size_t)m * p.ldc + n] = (acc[0][0][r] + e_bias) + e_add[r];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

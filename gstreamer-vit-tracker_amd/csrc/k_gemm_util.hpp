@@ -43,6 +43,15 @@ __device__ __forceinline__ f32v2_t gelu_erf2(f32v2_t x) {
     return __builtin_elementwise_fma(-a, e, r);
 }
 
+// A 4-B global load the compiler neither moves nor waits for: the caller puts an
+// `s_waitcnt vmcnt(..)` (with the destination as an in/out operand) before the first use and does not
+// touch the value in between.
+__device__ __forceinline__ float gload_f32_asm(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");
