@@ -334,12 +334,20 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
                     for (int q = 0; q < 4; ++q) {
                         const int nr = wc * WN + j * 32 + 8 * q + 4 * half;
                         float v[4];
+                        if constexpr (EPI == EPI_GELU_BF16) {      // element pairs: packed-f32 polynomial (k_gemm_util.hpp)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = acc[i][j][4 * q + e] + p.bias[n0 + nr + e];
-                            if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);
-                            else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
-                            else v[e] = x * scale;
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32v2_t g = gelu_erf2(f32v2_t{acc[i][j][4 * q + e] + p.bias[n0 + nr + e],
+                                                                    acc[i][j][4 * q + e + 1] + p.bias[n0 + nr + e + 1]});
+                                v[e] = g.x; v[e + 1] = g.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = acc[i][j][4 * q + e] + p.bias[n0 + nr + e];
+                                if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
+                                else v[e] = x * scale;
+                            }
                         }
                         const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                         if constexpr (FITS) {
