@@ -11,10 +11,20 @@ What it follows:
     definition — the reference runs an un-vendored RKNN model. It follows this
     build's specification in DESIGN.md §2/§3. PARITY UNPINNED against the reference.
 
-Quantisation points mirror the HIP path: GEMM operands are bf16 (weights are stored bf16;
-activations are rounded to bf16 exactly where the HIP kernels round them), accumulation,
-LayerNorm, softmax and the residual stream are float32. What remains different between the two
-is float32 summation order (and expf/erff last-bit differences).
+Quantisation points mirror the HIP path ("numerical specification v2"):
+GEMM operands are bf16 (weights are stored bf16; activations are rounded to bf16 exactly where the
+HIP kernels round them), accumulation, LayerNorm statistics and softmax are float32. The residual
+stream x is kept as a PAIR of bf16 tensors, hi = bf16(x) and lo = bf16(x - hi) (17 significant
+bits), and the two LayerNorms of a block are folded into the GEMM that consumes them: the GEMM's
+A operand is hi itself, its weights are W' = bf16(gamma * W), and the epilogue applies
+    y[m][n] = rstd[m] * (sum_k hi[m][k] W'[n][k] - mean[m] * s[n]) + c[n],
+    s[n] = sum_k W'[n][k],  c[n] = sum_k beta[k] W[n][k] + bias[n]
+with mean / rstd taken from the float32 value x had before it was split. What remains different
+between the two implementations is float32 summation order (and exp2 / GELU last-bit differences).
+
+`ROUNDING = False` turns every bf16 rounding into the identity (the folded form is then the plain
+pre-LN transformer in float32): that mode is what tests/test_oracle_crosscheck.py compares with the
+independent torch.nn.functional formulation in oracle/torch_ref.py.
 """
 from __future__ import annotations
 
@@ -84,8 +94,13 @@ def bf16_bits_to_f32(b):
         np.float32)
 
 
+ROUNDING = True     # False: every bf16 rounding of the NETWORK becomes the identity (cross-check mode)
+
+
 def bf16r(x):
     """round float32 values to the nearest bf16, returned as float32"""
+    if not ROUNDING:
+        return np.ascontiguousarray(x, dtype=np.float32)
     return bf16_bits_to_f32(f32_to_bf16_bits(x))
 
 
@@ -200,13 +215,42 @@ def preproc(frame: Frame, box, factor, out_size, patch, kpad, norm_a, norm_b):
 
 # ---- the network ------------------------------------------------------------------------------
 
-def layernorm(x, g, b, eps):
+def row_stats(x, eps):
+    """float32 two-pass mean / rstd of every row -> (mean [M,1], rstd [M,1])"""
     x = x.astype(np.float32)
     mean = x.mean(axis=-1, keepdims=True, dtype=np.float32)
     xc = x - mean
     var = (xc * xc).mean(axis=-1, keepdims=True, dtype=np.float32)
     rstd = (np.float32(1.0) / np.sqrt(var + np.float32(eps))).astype(np.float32)
-    return (xc * rstd) * g.reshape(1, -1) + b.reshape(1, -1)
+    return mean.astype(np.float32), rstd
+
+
+def layernorm(x, g, b, eps):
+    mean, rstd = row_stats(x, eps)
+    return ((x.astype(np.float32) - mean) * rstd) * g.reshape(1, -1) + b.reshape(1, -1)
+
+
+def split_residual(v):
+    """the residual stream as the bf16 pair the HIP path stores: hi = bf16(v), lo = bf16(v - hi)"""
+    v = v.astype(np.float32)
+    hi = bf16r(v)
+    lo = bf16r((v - hi).astype(np.float32))
+    return hi, lo
+
+
+def fold_layernorm(w, gamma, beta, bias):
+    """LayerNorm folded into the GEMM that consumes it: W' = bf16(gamma * W) (one float32 multiply,
+    one rounding), s[n] = sum_k W'[n][k], c[n] = sum_k beta[k] W[n][k] + bias[n] (float32)"""
+    wf = bf16r((w * gamma.reshape(1, -1)).astype(np.float32))
+    s = wf.sum(axis=1, dtype=np.float32)
+    c = (w @ beta.reshape(-1).astype(np.float32) + bias.reshape(-1)).astype(np.float32)
+    return wf, s, c
+
+
+def folded_linear(hi, mean, rstd, fold):
+    """rstd * (hi W'^T - mean s) + c, float32"""
+    wf, s, c = fold
+    return (rstd * ((hi @ wf.T) - mean * s.reshape(1, -1)) + c.reshape(1, -1)).astype(np.float32)
 
 
 def gelu(x):
@@ -296,30 +340,49 @@ class Model:
         self.gt, self.gs = self.T // self.patch, self.S // self.patch
         self.nt, self.ns = self.gt ** 2, self.gs ** 2
         self.eps = h["ln_eps"]
+        self._folds = {}
+
+    def folds(self, l):
+        """(qkv fold, fc1 fold) of layer l, built once per rounding mode"""
+        key = (l, ROUNDING)
+        if key not in self._folds:
+            t, p = self.t, f"l{l}."
+            self._folds[key] = (
+                fold_layernorm(t[p + "qkv_w"], t[p + "ln1_g"], t[p + "ln1_b"], t[p + "qkv_b"]),
+                fold_layernorm(t[p + "fc1_w"], t[p + "ln2_g"], t[p + "ln2_b"], t[p + "fc1_b"]))
+        return self._folds[key]
 
     def forward(self, patches_bits, taps=False):
-        """patches_bits [N, kpad] uint16 (template rows then search rows) -> dict"""
+        """patches_bits [N, kpad] uint16 (template rows then search rows) -> dict. Taps hold the
+        residual stream as the HIP path can reproduce it: hi + lo in float32."""
         t, D = self.t, self.D
         out = {}
         a = bf16_bits_to_f32(patches_bits)
-        x = a @ t["patch_w"].T + t["patch_b"] + t["pos"]
-        x = x.astype(np.float32)
+        v = (a @ t["patch_w"].T + t["patch_b"] + t["pos"]).astype(np.float32)
+        mean, rstd = row_stats(v, self.eps)
+        hi, lo = split_residual(v)
         if taps:
-            out["tokens0"] = x.copy()
+            out["tokens0"] = (hi + lo).astype(np.float32)
         for l in range(self.L):
             p = f"l{l}."
-            h1 = bf16r(layernorm(x, t[p + "ln1_g"], t[p + "ln1_b"], self.eps))
-            qkv = (h1 @ t[p + "qkv_w"].T + t[p + "qkv_b"]).astype(np.float32)
+            f_qkv, f_fc1 = self.folds(l)
+            qkv = folded_linear(hi, mean, rstd, f_qkv)
             q = bf16r(qkv[:, :D] * QK_SCALE)
             k = bf16r(qkv[:, D:2 * D])
-            v = bf16r(qkv[:, 2 * D:])
-            o = bf16r(attention(q, k, v, self.H))
-            x = (x + (o @ t[p + "proj_w"].T + t[p + "proj_b"])).astype(np.float32)
-            h2 = bf16r(layernorm(x, t[p + "ln2_g"], t[p + "ln2_b"], self.eps))
-            u = bf16r(gelu(h2 @ t[p + "fc1_w"].T + t[p + "fc1_b"]))
-            x = (x + (u @ t[p + "fc2_w"].T + t[p + "fc2_b"])).astype(np.float32)
+            vv = bf16r(qkv[:, 2 * D:])
+            o = bf16r(attention(q, k, vv, self.H))
+            v = ((o @ t[p + "proj_w"].T + t[p + "proj_b"]).astype(np.float32) +
+                 (hi + lo).astype(np.float32)).astype(np.float32)
+            mean, rstd = row_stats(v, self.eps)
+            hi, lo = split_residual(v)
+            u = bf16r(gelu(folded_linear(hi, mean, rstd, f_fc1)))
+            v = ((u @ t[p + "fc2_w"].T + t[p + "fc2_b"]).astype(np.float32) +
+                 (hi + lo).astype(np.float32)).astype(np.float32)
+            mean, rstd = row_stats(v, self.eps)
+            hi, lo = split_residual(v)
             if taps:
-                out[f"layer{l}"] = x.copy()
+                out[f"layer{l}"] = (hi + lo).astype(np.float32)
+        x = (hi + lo).astype(np.float32)
         feat = bf16r(layernorm(x[self.nt:], t["norm_g"], t["norm_b"], self.eps))
         out["feat"] = feat
         out.update(self.head(feat))
