@@ -172,9 +172,9 @@ def lib():
     L.vt_overlay_rgb8_device.argtypes = L.vt_overlay_nv12_device.argtypes
     L.vt_overlay_rgb8.argtypes = L.vt_overlay_nv12.argtypes
     u16p, fp = POINTER(c_uint16), POINTER(c_float)
-    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int]
+    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_float]
     L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
-    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int, c_int, c_int]
+    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp]
     L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
     L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
     L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
@@ -630,7 +630,11 @@ def overlay_rgb8(rgb: np.ndarray, cmds, device: int = 0) -> np.ndarray:
 
 # ---- operator-level entry points (numerics tests) -------------------------------------------
 
-def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1):
+def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1, rowstat=None,
+                 colsum=None, want_rowstat=False, eps=1e-6):
+    """vt_op_gemm_bf16. epilogue 0 / 1 / 4: the X-epilogues (x comes back as the sum of the bf16 pair the
+    engine stores; want_rowstat: also the finalized (rstd, -mean * rstd) per row -> (x, rowstat));
+    2 / 3: GELU / ReLU to bf16, with a folded LayerNorm if rowstat [M,2] and colsum [N] are given"""
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
     w_bits = np.ascontiguousarray(w_bits, np.uint16)
     M, K = a_bits.shape
@@ -638,9 +642,14 @@ def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1
     c = np.zeros((M, N), np.float32) if c_init is None else np.ascontiguousarray(c_init,
                                                                                  np.float32).copy()
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rs = None if rowstat is None else np.ascontiguousarray(rowstat, np.float32)
+    cs = None if colsum is None else np.ascontiguousarray(colsum, np.float32)
+    ro = np.zeros((M, 2), np.float32) if want_rowstat else None
     _check(lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
-                                 _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue, cfg))
-    return c
+                                 _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue, cfg,
+                                 _f32(rs) if rs is not None else None, _f32(cs) if cs is not None else None,
+                                 _f32(ro) if ro is not None else None, eps))
+    return (c, ro) if want_rowstat else c
 
 
 def op_gemm_bench(M, N, K, epilogue, cfg=-1, iters=50, device=0) -> float:
@@ -649,15 +658,19 @@ def op_gemm_bench(M, N, K, epilogue, cfg=-1, iters=50, device=0) -> float:
     return float(us.value)
 
 
-def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0, cfg=-1, vt_perm=0):
+def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0, cfg=-1, vt_perm=0, rowstat=None,
+                colsum=None):
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
     w_bits = np.ascontiguousarray(w_bits, np.uint16)
     bias = np.ascontiguousarray(bias, np.float32)
     npad = (tokens + 63) // 64 * 64
     qk = np.empty((B * tokens, 2 * D), np.float32)
     vt = np.empty((B * (D // 64), 64, npad), np.float32)
+    rs = None if rowstat is None else np.ascontiguousarray(rowstat, np.float32)
+    cs = None if colsum is None else np.ascontiguousarray(colsum, np.float32)
     _check(lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),
-                                _f32(vt), B, tokens, D, cfg, vt_perm))
+                                _f32(vt), B, tokens, D, cfg, vt_perm,
+                                _f32(rs) if rs is not None else None, _f32(cs) if cs is not None else None))
     return qk, vt
 
 

@@ -241,69 +241,119 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
+        // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics ------------------------
+        // The accumulators (row on the lane, 4 consecutive columns per register quad) are staged as a
+        // float32 tile [BM][BN] in the dead operand ring (16-B chunk c of row r at c ^ (r & 7)) and written
+        // out row-wise, 8 consecutive columns per lane: addend, bias, statistics of the 32-column chunk a
+        // quad of lanes covers, split into hi / lo, two 16-B stores. PIECES 8-column groups per thread.
+        constexpr int NT = WVM * WVN * 64, CPR8 = BN / 8, PIECES = BM * BN / 8 / NT;
+        static_assert(BM * BN * 4 <= ring_bytes(NS, BM, BN, BK), "f32 tile must fit the operand ring");
+        static_assert(NT % CPR8 == 0 && PIECES >= 1, "a thread's column group is the same for all its pieces");
+        const int tid = threadIdx.x;
+        const int ch8 = tid % CPR8, n8 = n0 + ch8 * 8;
         // 64x64 tiles (small batches: a one-stream GEMM is ~8 us of mostly dependent latencies): the
-        // epilogue's addends (old residual / positional rows) and the bias do not depend on the product,
-        // so they are fetched BEFORE the main loop and their latency runs under it instead of being a
-        // round trip at the end of the kernel. Inline-asm global loads: plain loads are sunk to their use
-        // behind the loop by hipcc, volatile ones are each followed by vmcnt(0). Being the oldest entries
-        // of the in-order vector-memory queue they are retired by the loop's first counted wait; the
-        // registers are not touched until the vmcnt(0) below. Rows are clamped: every address is valid.
-        constexpr bool EARLY = TM * TN == 1 && (EPI == EPI_F32_POS || EPI == EPI_RESID);
-        float e_bias = 0.0f, e_add[16];
+        // epilogue's addends (old residual pair / positional rows) and the bias do not depend on the
+        // product, so they are fetched BEFORE the main loop and their latency runs under it instead of
+        // being a round trip at the end of the kernel. Inline-asm global loads: plain loads are sunk to
+        // their use behind the loop by hipcc, volatile ones are each followed by vmcnt(0). Being the oldest
+        // entries of the in-order vector-memory queue they are retired by the loop's first counted wait;
+        // the registers are not touched until the vmcnt(0) below. Rows are clamped: every address is valid.
+        constexpr bool EARLY = TM * TN == 1 && EPI != EPI_F32;
+        u32x4_t e_a[PIECES][2], e_bias[2];
         if constexpr (EARLY) {
-            const int n = n0 + wc * WN + l31;
-            if (p.bias) e_bias = gload_f32_asm(p.bias + n);
+            e_bias[0] = gload_b128_asm(p.bias + n8);
+            e_bias[1] = gload_b128_asm(p.bias + n8 + 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM + acc_row(r, half);
+            for (int k = 0; k < PIECES; ++k) {
+                const int m = m0 + (tid + k * NT) / CPR8;
                 const int mc = m < p.M ? m : p.M - 1;
-                e_add[r] = gload_f32_asm(EPI == EPI_F32_POS ? p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n
-                                                            : p.Cf + (size_t)mc * p.ldc + n);
+                if constexpr (EPI == EPI_F32_POS) {
+                    const float* src = p.pos + (size_t)(mc % p.pos_rows) * p.ldx + n8;
+                    e_a[k][0] = gload_b128_asm(src);
+                    e_a[k][1] = gload_b128_asm(src + 4);
+                } else {
+                    e_a[k][0] = gload_b128_asm(p.Xh + (size_t)mc * p.ldx + n8);
+                    e_a[k][1] = gload_b128_asm(p.Xl + (size_t)mc * p.ldx + n8);
+                }
             }
         }
-        gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
+        gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true>(p, smem, m0, n0, acc);
+        __syncthreads();                       // every wave has finished reading the ring
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mr = wr * WM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = (wc * WN + j * 32 + 8 * q + 4 * half) >> 2;      // 16-B chunk of the row
+                    *reinterpret_cast<f32x4_t*>(smem + mr * (BN * 4) + ((c ^ (mr & 7)) << 4)) =
+                        f32x4_t{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+        }
+        __syncthreads();
+        float bias8[8];
         if constexpr (EARLY) {
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(e_bias), "+v"(e_add[0]), "+v"(e_add[1]), "+v"(e_add[2]), "+v"(e_add[3]), "+v"(e_add[4]),
-                           "+v"(e_add[5]), "+v"(e_add[6]), "+v"(e_add[7]), "+v"(e_add[8]), "+v"(e_add[9]), "+v"(e_add[10]),
-                           "+v"(e_add[11]), "+v"(e_add[12]), "+v"(e_add[13]), "+v"(e_add[14]), "+v"(e_add[15])
-                         :
-                         : "memory");
-            const int n = n0 + wc * WN + l31;
+            if constexpr (PIECES == 2)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_a[0][1]),
+                             "+v"(e_a[1][0]), "+v"(e_a[1][1]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_a[0][1]) : : "memory");
+            static_assert(!EARLY || PIECES <= 2, "64x64 tile, 256 threads");
+            const uint32_t b[8] = {e_bias[0][0], e_bias[0][1], e_bias[0][2], e_bias[0][3], e_bias[1][0], e_bias[1][1], e_bias[1][2], e_bias[1][3]};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM + acc_row(r, half);
-                if (m < p.M) p.Cf[(size_t)m * p.ldc + n] = (acc[0][0][r] + e_bias) + e_add[r];
-            }
-            return;
+            for (int e = 0; e < 8; ++e) bias8[e] = __uint_as_float(b[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = p.bias ? p.bias[n8 + e] : 0.0f;
         }
+        const int nchunk = p.N / VT_STAT_CHUNK;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int k = 0; k < PIECES; ++k) {
+            const int row = (tid + k * NT) / CPR8, m = m0 + row;
+            const int mc = m < p.M ? m : p.M - 1;
+            const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(smem + row * (BN * 4) + (((2 * ch8) ^ (row & 7)) << 4));
+            const f32x4_t f1 = *reinterpret_cast<const f32x4_t*>(smem + row * (BN * 4) + (((2 * ch8 + 1) ^ (row & 7)) << 4));
+            float add[8];
+            if constexpr (EPI == EPI_F32) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wc * WN + j * 32 + l31;
-                const float bias = p.bias ? p.bias[n] : 0.0f;
-                // All 16 reads of the old value / positional row are issued before the first use
-                // (rows clamped so every address is valid): a load inside the `m < M` branch makes
-                // hipcc wait vmcnt(0) per element, 16 serial L2 round trips per tile.
-                float addend[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * WM + i * 32 + acc_row(r, half);
-                    const int mc = m < p.M ? m : p.M - 1;
-                    if constexpr (EPI == EPI_F32_POS)
-                        addend[r] = p.pos[(size_t)(mc % p.pos_rows) * p.ldc + n];
-                    else if constexpr (EPI == EPI_RESID)
-                        addend[r] = p.Cf[(size_t)mc * p.ldc + n];
-                    else
-                        addend[r] = 0.0f;
+                for (int e = 0; e < 8; ++e) add[e] = 0.0f;
+            } else if constexpr (EPI == EPI_F32_POS) {
+                u32x4_t a0, a1;
+                if constexpr (EARLY) { a0 = e_a[k][0]; a1 = e_a[k][1]; }
+                else {
+                    const float* src = p.pos + (size_t)(mc % p.pos_rows) * p.ldx + n8;
+                    a0 = *reinterpret_cast<const u32x4_t*>(src); a1 = *reinterpret_cast<const u32x4_t*>(src + 4);
                 }
+                const uint32_t u[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * WM + i * 32 + acc_row(r, half);
-                    if (m < p.M) p.Cf[(size_t)m * p.ldc + n] = (acc[i][j][r] + bias) + addend[r];
+                for (int e = 0; e < 8; ++e) add[e] = __uint_as_float(u[e]);
+            } else {
+                u32x4_t hi, lo;
+                if constexpr (EARLY) { hi = e_a[k][0]; lo = e_a[k][1]; }
+                else {
+                    hi = *reinterpret_cast<const u32x4_t*>(p.Xh + (size_t)mc * p.ldx + n8);
+                    lo = *reinterpret_cast<const u32x4_t*>(p.Xl + (size_t)mc * p.ldx + n8);
                 }
+                x_join8(hi, lo, add);
             }
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = (f0[e] + bias8[e]) + add[e];
+                x[4 + e] = (f1[e] + bias8[4 + e]) + add[4 + e];
+            }
+            float csum, cm2;
+            x_chunk_stats(x, csum, cm2);
+            u32x4_t hi, lo;
+            x_split8(x, hi, lo);
+            if (m < p.M) {
+                *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
+                *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
+                if (p.cstat && (ch8 & 3) == 0)
+                    p.cstat[(size_t)m * nchunk + (n8 / VT_STAT_CHUNK)] = make_float2(csum, cm2);
+            }
+        }
     } else {
         // ---- bf16 outputs -----------------------------------------------------------------------
         // The accumulator layout gives each lane 4 consecutive outputs (8 B) in 32 different rows;
@@ -325,28 +375,37 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
+            // folded LayerNorm: y = a_r * acc + (b_r * colsum[n] + bias[n]); without one a_r = 1, b_r = 0
+            // and fma(1, acc, bias) = acc + bias exactly
+            const bool ln = p.rowstat != nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mr = wr * WM + i * 32 + l31;
+                float2 rs = make_float2(1.0f, 0.0f);
+                if (ln) rs = p.rowstat[m0 + mr < p.M ? m0 + mr : p.M - 1];
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int nr = wc * WN + j * 32 + 8 * q + 4 * half;
-                        float v[4];
+                        float v[4], y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = ln ? __builtin_fmaf(rs.y, p.colsum[n0 + nr + e], p.bias[n0 + nr + e])
+                                               : p.bias[n0 + nr + e];
+                            y[e] = __builtin_fmaf(rs.x, acc[i][j][4 * q + e], t);
+                        }
                         if constexpr (EPI == EPI_GELU_BF16) {      // element pairs: packed-f32 polynomial (k_gemm_util.hpp)
 #pragma unroll
                             for (int e = 0; e < 4; e += 2) {
-                                const f32v2_t g = gelu_erf2(f32v2_t{acc[i][j][4 * q + e] + p.bias[n0 + nr + e],
-                                                                    acc[i][j][4 * q + e + 1] + p.bias[n0 + nr + e + 1]});
+                                const f32v2_t g = gelu_erf2(f32v2_t{y[e], y[e + 1]});
                                 v[e] = g.x; v[e + 1] = g.y;
                             }
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float x = acc[i][j][4 * q + e] + p.bias[n0 + nr + e];
-                                if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
-                                else v[e] = x * scale;
+                                if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(y[e], 0.0f);
+                                else v[e] = y[e] * scale;
                             }
                         }
                         const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -386,19 +445,25 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int nr = wc * WN + j * 32 + l31;
-                    const float bias = p.bias[n0 + nr];
+                    const bool ln = p.rowstat != nullptr;
+                    const float bias = p.bias[n0 + nr], cs = ln ? p.colsum[n0 + nr] : 0.0f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int mr = wr * WM + i * 32 + 8 * q + 4 * half;
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {      // rows mr .. mr+3 (tokens), this lane's column d
+                            float2 rs = make_float2(1.0f, 0.0f);
+                            if (ln) rs = p.rowstat[m0 + mr + e < p.M ? m0 + mr + e : p.M - 1];
+                            y[e] = __builtin_fmaf(rs.x, acc[i][j][4 * q + e], __builtin_fmaf(rs.y, cs, bias));
+                        }
                         // permuted Vt layout (attention mode 3): the 4-token run moves inside its
                         // group of 16. Streams on 16-token boundaries: permute the tile-local index
                         // here; otherwise (e.g. 980 tokens) each run is placed by its own stream's
                         // token index when it is written out
                         const bool perm_general = p.vt_perm && (p.tokens & 15);
                         const int mp = (p.vt_perm && !perm_general) ? attn_perm16(mr) : mr;
-                        const uint2 pk = make_uint2(
-                            pack_bf16x2(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias),
-                            pack_bf16x2(acc[i][j][4 * q + 2] + bias, acc[i][j][4 * q + 3] + bias));
+                        const uint2 pk = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
                         if constexpr (FITS) {
                             *reinterpret_cast<uint2*>(smem + nr * STRIDE + mp * 2) = pk;
                         } else if (m0 + mr < p.M) {
@@ -584,6 +649,10 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
         return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
         return hipErrorInvalidValue;
+    const bool x_epi = epilogue == EPI_F32_POS || epilogue == EPI_RESID || epilogue == EPI_F32;
+    if (x_epi && (!a.Xh || !a.Xl || (a.ldx & 7) || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1))))
+        return hipErrorInvalidValue;
+    if (!x_epi && (!a.bias || (a.rowstat && !a.colsum))) return hipErrorInvalidValue;
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
     if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
     if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);

@@ -79,7 +79,6 @@ __device__ __forceinline__ void lds_write64_asm(uint32_t addr, uint32_t lo, uint
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 template <int OFF>
 __device__ __forceinline__ void lds_read128_asm(u32x4_t& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
@@ -404,22 +403,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
         if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
         else g256_mainloop<true>(p, smem, m0, n0, acc);
-        // two passes (i = 0, 1) of 128 rows x 256 f32: row lr = wr*64 + mf*16 + l15 of the pass,
-        // 16-B chunk ch of the row stored at ch ^ (lr & 7)
-        const int ch_r = tid & 63, n = n0 + ch_r * 4;
-        f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-        // row `it` (0..15) of pass i that this wave writes out: pass row lr = it*8 + wave
-        auto out_row = [&](int i, int it) { const int lr = it * 8 + wave; return m0 + (lr >> 6) * 128 + i * 64 + (lr & 63); };
-        auto load_addend = [&](int i, int it) -> f32x4_t {
+        // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics (vt_common.hpp) ----------
+        // Two passes (i = 0, 1) of 128 rows x 256 f32 staged in LDS: row lr = wr*64 + mf*16 + l15 of the
+        // pass, 16-B chunk ch of the row stored at ch ^ (lr & 7). Written out row-wise, 8 consecutive
+        // columns per lane (two rows per wave instruction: 512 B of hi and 512 B of lo per row): addend,
+        // bias, statistics of the 32-column chunk a quad of lanes covers, split, two 16-B stores.
+        // The residual read-modify-write is HBM traffic (128 KB in + 128 KB out per tile) on top of the
+        // main loop: the addend loads of a whole pass (8 row pairs per wave, 64 VGPRs - the operand
+        // fragments are dead) are issued BEFORE the accumulators are staged, and those of pass 1 before
+        // pass 0 is written out, so their latency runs under LDS staging and the stores.
+        const int c8 = lane & 31, rsub = lane >> 5, n8 = n0 + c8 * 8;
+        float bias8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = p.bias ? p.bias[n8 + e] : 0.0f;
+        const int nchunk = p.N / VT_STAT_CHUNK;
+        // row pair `it` (0..7) of pass i that this wave writes out: pass rows lr = it*16 + wave*2 + rsub
+        auto out_row = [&](int i, int it) { const int lr = it * 16 + wave * 2 + rsub; return m0 + (lr >> 6) * 128 + i * 64 + (lr & 63); };
+        auto load_addend = [&](int i, int it, u32x4_t& a0, u32x4_t& a1) {
             const int m = out_row(i, it);
             const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
-            if constexpr (EPI == EPI_RESID)
-                return *reinterpret_cast<const f32x4_t*>(p.Cf + (size_t)mc * p.ldc + n);
-            else if constexpr (EPI == EPI_F32_POS)
-                return *reinterpret_cast<const f32x4_t*>(p.pos + (size_t)(mc % p.pos_rows) * p.ldc + n);
-            else
-                return f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_RESID) {
+                a0 = *reinterpret_cast<const u32x4_t*>(p.Xh + (size_t)mc * p.ldx + n8);
+                a1 = *reinterpret_cast<const u32x4_t*>(p.Xl + (size_t)mc * p.ldx + n8);
+            } else if constexpr (EPI == EPI_F32_POS) {
+                const float* src = p.pos + (size_t)(mc % p.pos_rows) * p.ldx + n8;
+                a0 = *reinterpret_cast<const u32x4_t*>(src);
+                a1 = *reinterpret_cast<const u32x4_t*>(src + 4);
+            } else {
+                a0 = u32x4_t{0u, 0u, 0u, 0u}; a1 = a0;
+            }
         };
         auto stage_pass = [&](int i) {
 #pragma unroll
@@ -435,58 +447,49 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     }
             }
         };
-        if constexpr (VER == 2) {
-            // The residual read-modify-write is HBM traffic (256 KB in + 256 KB out per tile) on top of
-            // a 20 us main loop: the addend loads of a whole pass (16 rows per wave, 64 VGPRs - the
-            // operand fragments are dead) are issued BEFORE the accumulators are staged, and those
-            // of pass 1 before pass 0 is written out, so their latency runs under LDS staging and
-            // the stores instead of in four serial load->wait->store batches.
-            f32x4_t ad0[16], ad1[16];
+        auto write_pass = [&](int i, const u32x4_t (&ad)[8][2]) {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) ad0[it] = load_addend(0, it);
-            __syncthreads();
-            stage_pass(0);
-            __syncthreads();
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 16 + wave * 2 + rsub, m = out_row(i, it);
+                const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + (((2 * c8) ^ (lr & 7)) << 4));
+                const f32x4_t f1 = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + (((2 * c8 + 1) ^ (lr & 7)) << 4));
+                float add[8], x[8];
+                if constexpr (EPI == EPI_RESID) {
+                    x_join8(ad[it][0], ad[it][1], add);
+                } else {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) ad1[it] = load_addend(1, it);
+                    for (int e = 0; e < 4; ++e) { add[e] = __uint_as_float(ad[it][0][e]); add[4 + e] = __uint_as_float(ad[it][1][e]); }
+                }
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int lr = it * 8 + wave, m = out_row(0, it);
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
-                if (m < p.M) *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + ad0[it];
-            }
-            __syncthreads();
-            stage_pass(1);
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int lr = it * 8 + wave, m = out_row(1, it);
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
-                if (m < p.M) *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + ad1[it];
-            }
-        } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __syncthreads();
-            stage_pass(i);
-            __syncthreads();
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {      // 8 rows per batch: all addend loads first
-                f32x4_t addend[8];
-#pragma unroll
-                for (int it = 0; it < 8; ++it) addend[it] = load_addend(i, hb * 8 + it);
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int lr = (hb * 8 + it) * 8 + wave;
-                    const int m = out_row(i, hb * 8 + it);
-                    const f32x4_t v =
-                        *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + ((ch_r ^ (lr & 7)) << 4));
-                    if (m < p.M)
-                        *reinterpret_cast<f32x4_t*>(p.Cf + (size_t)m * p.ldc + n) = (v + bias4) + addend[it];
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (f0[e] + bias8[e]) + add[e];
+                    x[4 + e] = (f1[e] + bias8[4 + e]) + add[4 + e];
+                }
+                float csum, cm2;
+                x_chunk_stats(x, csum, cm2);
+                u32x4_t hi, lo;
+                x_split8(x, hi, lo);
+                if (m < p.M) {
+                    *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
+                    *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
+                    if (p.cstat && (c8 & 3) == 0)
+                        p.cstat[(size_t)m * nchunk + (n8 / VT_STAT_CHUNK)] = make_float2(csum, cm2);
                 }
             }
-        }
-        }
+        };
+        u32x4_t ad0[8][2], ad1[8][2];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) load_addend(0, it, ad0[it][0], ad0[it][1]);
+        __syncthreads();
+        stage_pass(0);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) load_addend(1, it, ad1[it][0], ad1[it][1]);
+        write_pass(0, ad0);
+        __syncthreads();
+        stage_pass(1);
+        __syncthreads();
+        write_pass(1, ad1);
     } else {
         bool v_tile = false;
         float scale = 1.0f;
@@ -498,19 +501,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
             else g256_mainloop<true>(p, smem, m0, n0, acc);
             // whole tile as [256 rows][512 B]; 8-B chunk c8 of row r stored at c8 ^ ((r & 7) << 1)
-            f32x4_t bias4[2][2];
+            // folded LayerNorm (vt_common.hpp): y = a_r * acc + (b_r * colsum[n] + bias[n]); without one
+            // a_r = 1, b_r = 0 and fma(1, acc, bias) = acc + bias exactly
+            const bool ln = p.rowstat != nullptr;
+            f32x4_t bias4[2][2], cs4[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
+                for (int nf = 0; nf < 2; ++nf) {
                     bias4[j][nf] = *reinterpret_cast<const f32x4_t*>(
                         p.bias + n0 + wc * 64 + j * 32 + nf * 16 + 4 * q);
+                    cs4[j][nf] = ln ? *reinterpret_cast<const f32x4_t*>(p.colsum + n0 + wc * 64 + j * 32 + nf * 16 + 4 * q)
+                                    : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf) {
                     const int row = wr * 128 + i * 64 + mf * 16 + l15;
+                    float2 rs = make_float2(1.0f, 0.0f);
+                    if (ln) rs = p.rowstat[m0 + row < p.M ? m0 + row : p.M - 1];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -519,7 +530,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float x = acc[i][mf][j][nf][e] + bias4[j][nf][e];
+                                const float x = __builtin_fmaf(rs.x, acc[i][mf][j][nf][e],
+                                                               __builtin_fmaf(rs.y, cs4[j][nf][e], bias4[j][nf][e]));
                                 if constexpr (EPI == EPI_GELU_BF16) v[e] = gelu_erf(x);
                                 else if constexpr (EPI == EPI_RELU_BF16) v[e] = fmaxf(x, 0.0f);
                                 else v[e] = x * scale;
@@ -572,7 +584,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const int drow = wc * 64 + j * 32 + nf * 16 + l15;
-                    const float bias = p.bias[n0 + drow];
+                    const bool ln = p.rowstat != nullptr;
+                    const float bias = p.bias[n0 + drow], cs = ln ? p.colsum[n0 + drow] : 0.0f;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -584,9 +597,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                             const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
                             const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
                             const f32x4_t a = acc[i][mf][j][nf];
+                            float y[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {     // tokens 4q .. 4q+3 of this 16-row block
+                                const int mrow = m0 + wr * 128 + i * 64 + mf * 16 + 4 * q + e;
+                                float2 rs = make_float2(1.0f, 0.0f);
+                                if (ln) rs = p.rowstat[mrow < p.M ? mrow : p.M - 1];
+                                y[e] = __builtin_fmaf(rs.x, a[e], __builtin_fmaf(rs.y, cs, bias));
+                            }
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
-                                make_uint2(pack_bf16x2(a[0] + bias, a[1] + bias),
-                                           pack_bf16x2(a[2] + bias, a[3] + bias));
+                                make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
                         }
                 }
             __syncthreads();
@@ -834,13 +854,27 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
             int te = tid;
             asm volatile("" : "+v"(te));
             const int el = te & 63, e15 = el & 15, eq = el >> 4;
-            f32x4_t bias4[2][2];
+            // folded LayerNorm (vt_common.hpp): y = a_r * acc + (b_r * colsum[n] + bias[n]); the row terms of
+            // the lane's eight rows (one per 16-row block) and the column sums are fetched here, where the
+            // vector-memory queue is empty (the main loop's last wait was vmcnt(0)): the compiler's wait for
+            // them drains nothing else. Without a LayerNorm a_r = 1, b_r = 0: fma(1, acc, bias) = acc + bias.
+            const bool ln = p.rowstat != nullptr;
+            f32x4_t bias4[2][2], cs4[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
+                for (int nf = 0; nf < 2; ++nf) {
                     bias4[j][nf] = *reinterpret_cast<const f32x4_t*>(
                         p.bias + tn0 + wc * 64 + j * 32 + nf * 16 + 4 * eq);
+                    cs4[j][nf] = ln ? *reinterpret_cast<const f32x4_t*>(p.colsum + tn0 + wc * 64 + j * 32 + nf * 16 + 4 * eq)
+                                    : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+            float2 rs8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int mrow = tm0 + wr * 128 + k * 16 + e15;
+                rs8[k] = ln ? p.rowstat[mrow < p.M ? mrow : p.M - 1] : make_float2(1.0f, 0.0f);
+            }
             char* ow = smem + G256P_STAGE + wave * 4096;
             const int rr = el >> 3, rc = el & 7;       // read-out: 8 rows per instruction, 16-B chunk rc
             bf16_t* const obase = (EPI == EPI_QKV)
@@ -874,8 +908,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     {                                                                                            \
         f32v2_t v[2];                                                                            \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                          \
-            const f32v2_t x = f32v2_t{acc[(K) >> 2][(K) & 3][J][NF][2 * e], acc[(K) >> 2][(K) & 3][J][NF][2 * e + 1]} + \
-                              f32v2_t{bias4[J][NF][2 * e], bias4[J][NF][2 * e + 1]};             \
+            const f32v2_t t = __builtin_elementwise_fma(f32v2_t{rs8[K].y, rs8[K].y},                  \
+                                                        f32v2_t{cs4[J][NF][2 * e], cs4[J][NF][2 * e + 1]}, \
+                                                        f32v2_t{bias4[J][NF][2 * e], bias4[J][NF][2 * e + 1]}); \
+            const f32v2_t x = __builtin_elementwise_fma(f32v2_t{rs8[K].x, rs8[K].x},                  \
+                f32v2_t{acc[(K) >> 2][(K) & 3][J][NF][2 * e], acc[(K) >> 2][(K) & 3][J][NF][2 * e + 1]}, t); \
             if constexpr (EPI == EPI_GELU_BF16) v[e] = VT_GELU2(x);                              \
             else if constexpr (EPI == EPI_RELU_BF16) v[e] = f32v2_t{fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)}; \
             else v[e] = x * scale;                                                               \
@@ -920,7 +957,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const int drow = wc * 64 + j * 32 + nf * 16 + l15;
-                    const float bias = p.bias[tn0 + drow];
+                    const bool ln = p.rowstat != nullptr;
+                    const float bias = p.bias[tn0 + drow], cs = ln ? p.colsum[tn0 + drow] : 0.0f;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -928,9 +966,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
                             const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
                             const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
                             const f32x4_t a = acc[i][mf][j][nf];
+                            float y[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {     // tokens 4q .. 4q+3 of this 16-row block
+                                const int mrow = tm0 + wr * 128 + i * 64 + mf * 16 + 4 * q + e;
+                                float2 rs = make_float2(1.0f, 0.0f);
+                                if (ln) rs = p.rowstat[mrow < p.M ? mrow : p.M - 1];
+                                y[e] = __builtin_fmaf(rs.x, a[e], __builtin_fmaf(rs.y, cs, bias));
+                            }
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
-                                make_uint2(pack_bf16x2(a[0] + bias, a[1] + bias),
-                                           pack_bf16x2(a[2] + bias, a[3] + bias));
+                                make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
                         }
                 }
             __syncthreads();
@@ -1056,15 +1101,16 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t 
         case EPI_F32_POS:
         case EPI_RESID:
         case EPI_F32:
-            if ((a.ldc & 3) || !a.Cf) return hipErrorInvalidValue;
+            if ((a.ldx & 7) || !a.Xh || !a.Xl || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1)))
+                return hipErrorInvalidValue;
             break;
         case EPI_GELU_BF16:
         case EPI_RELU_BF16:
-            if ((a.ldcb & 7) || !a.Cb || !a.bias) return hipErrorInvalidValue;
+            if ((a.ldcb & 7) || !a.Cb || !a.bias || (a.rowstat && !a.colsum)) return hipErrorInvalidValue;
             break;
         case EPI_QKV:
             if (a.D % 256 != 0 || a.N != 3 * a.D || (a.tokens & 3) ||
-                (a.npad & 3) || !a.bias)
+                (a.npad & 3) || !a.bias || (a.rowstat && !a.colsum))
                 return hipErrorInvalidValue;
             break;
         default: return hipErrorInvalidValue;

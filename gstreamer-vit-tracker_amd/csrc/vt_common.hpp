@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // one device-resident input frame (mirrors vt_frame, 64-bit pointers)
 struct FrameDesc {
@@ -55,23 +56,35 @@ struct ModelDims {
 // (the attention kernels use v_exp_f32 = 2^x directly); float(log2 e) / 8 is exact in float32
 #define ATT_Q_SCALE (0.125f * 1.4426950408889634f)
 
+// The residual stream x is stored as a PAIR of bf16 matrices: Xh = bf16(x), Xl = bf16(x - Xh) (17
+// significant bits; Xh alone is the A operand of the GEMM that consumes the following LayerNorm). The
+// three epilogues that produce x (X-epilogues) also emit, per row and per 32-column chunk, the partial
+// statistics (sum, sum of squared deviations from the chunk mean) of the float32 value before the split:
+// rowstat_finalize turns them into the (rstd, -mean * rstd) the consuming GEMM's epilogue applies.
 enum GemmEpilogue {
-    EPI_F32_POS = 0,   // C f32 = acc + bias + pos[m % pos_rows]      (patch embed)
-    EPI_RESID = 1,     // C f32 += acc + bias                          (proj, fc2)
-    EPI_GELU_BF16 = 2, // Cb bf16 = gelu(acc + bias)                   (fc1)
-    EPI_RELU_BF16 = 3, // Cb bf16 = relu(acc + bias)                   (head convs)
+    EPI_F32_POS = 0,   // x = (acc + bias) + pos[m % pos_rows] -> Xh, Xl, cstat   (patch embed)
+    EPI_RESID = 1,     // x = (acc + bias) + (Xh + Xl)         -> Xh, Xl, cstat   (proj, fc2)
+    EPI_GELU_BF16 = 2, // Cb bf16 = gelu(y)                                        (fc1)
+    EPI_RELU_BF16 = 3, // Cb bf16 = relu(y)                                        (head convs)
     EPI_QKV = 4,       // q*ATT_Q_SCALE,k -> qk[M][2D] bf16; v -> Vt[b][h][64][npad]
-    EPI_F32 = 5        // C f32 = acc + bias                           (operator tests)
+    EPI_F32 = 5        // x = acc + bias                       -> Xh, Xl, cstat   (operator tests)
 };
+// y of the bf16 epilogues: acc + bias, or with a folded LayerNorm (rowstat != null)
+//     y[m][n] = rowstat[m].x * acc + (rowstat[m].y * colsum[n] + bias[n])
+// where the weights are W' = bf16(gamma * W), colsum[n] = sum_k W'[n][k], bias[n] = sum_k beta[k] W[n][k] + b[n]
+#define VT_STAT_CHUNK 32
 
 struct GemmArgs {
     const bf16_t* A; int lda;     // [M][K] row-major bf16
     const bf16_t* W; int ldw;     // [N][K] row-major bf16 (one output feature per row)
     const float* bias;            // [N]
     int M, N, K;
-    float* Cf; int ldc;           // f32 output / residual stream
+    bf16_t* Xh; bf16_t* Xl; int ldx;   // X-epilogues: the residual stream pair [M][ldx] (EPI_RESID: read, then written)
+    float2* cstat;                // X-epilogues: [M][N / 32] chunk partials (sum, M2), or null
     bf16_t* Cb; int ldcb;         // bf16 output
-    const float* pos; int pos_rows;
+    const float* pos; int pos_rows;     // EPI_F32_POS: [pos_rows][ldx] f32
+    const float2* rowstat;        // bf16 epilogues: folded LayerNorm row terms [M] (rstd, -mean * rstd), or null
+    const float* colsum;          // ... and its column sums [N]
     bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
     int vt_perm;                  // Vt key order inside each group of 16: 0 natural, 1 attn_perm16 (attention mode 3)
     unsigned long long* dbg;      // diagnostic builds only (VT_STAMPS): per-wave cycle sums
@@ -100,6 +113,17 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
                             int rows, int D, int group, int in_stride, int in_off, float eps,
                             hipStream_t st);
+// the same on the split residual stream: x = xh + xl
+hipError_t launch_layernorm_split(const bf16_t* xh, const bf16_t* xl, const float* gamma, const float* beta,
+                                  bf16_t* y, int rows, int D, int group, int in_stride, int in_off,
+                                  float eps, hipStream_t st);
+// rowstat[m] = (rstd, -mean * rstd) from the chunk partials of an X-epilogue (D = 32 * nchunk columns)
+hipError_t launch_rowstat_finalize(const float2* cstat, float2* rowstat, int M, int nchunk, float eps,
+                                   hipStream_t st);
+// LayerNorm folded into the weights of the GEMM that consumes it (once, at engine creation):
+// Wf[n][k] = bf16(gamma[k] * W[n][k]); colsum[n] = sum_k Wf[n][k]; cvec[n] = sum_k beta[k] W[n][k] + bias[n]
+hipError_t launch_fold_layernorm(const bf16_t* W, const float* gamma, const float* beta, const float* bias,
+                                 bf16_t* Wf, float* colsum, float* cvec, int N, int K, hipStream_t st);
 
 // out[M][D] bf16 = softmax(q k^T) v, q/k rows in qk[M][2D], v transposed in vt[B*H][64][npad]
 hipError_t launch_attention(const bf16_t* qk, const bf16_t* vt, bf16_t* out, int B, int tokens,

@@ -86,6 +86,10 @@ struct TensorRef {
 struct LayerW {
     const float *ln1_g, *ln1_b, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
     const bf16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    // LayerNorm 1 / 2 folded into the QKV / fc1 GEMM (launch_fold_layernorm, once per engine):
+    // weights bf16(gamma * W), their column sums, and beta W^T + bias
+    const bf16_t *qkv_wf = nullptr, *fc1_wf = nullptr;
+    const float *qkv_cs = nullptr, *qkv_c = nullptr, *fc1_cs = nullptr, *fc1_c = nullptr;
 };
 
 struct KernelStat {
@@ -111,7 +115,7 @@ struct Profiler {
 
 // kernel-family label of a GEMM launch (built only when a profiler is attached)
 static const char* gemm_name(int epi, int M, int N, int K) {
-    static const char* tags[] = {"f32pos", "resid", "gelu", "relu", "qkv", "f32"};
+    static const char* tags[] = {"xpos", "xresid", "gelu", "relu", "qkv", "x"};
     static thread_local char buf[96];
     snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s_n%dk%d", tags[epi], gemm_config_name(gemm_pick_config(M, N, K, epi)), N, K);
     return buf;
@@ -128,10 +132,14 @@ struct Engine {
     std::map<std::string, TensorRef> tens;
     std::vector<LayerW> layers;
     // activations
-    bf16_t *d_patches = nullptr, *d_ln = nullptr, *d_qk = nullptr, *d_vt = nullptr,
+    bf16_t *d_patches = nullptr, *d_qk = nullptr, *d_vt = nullptr,
            *d_attn = nullptr, *d_mlp = nullptr, *d_feat = nullptr, *d_ta = nullptr,
            *d_tb = nullptr, *d_zeros = nullptr;     // d_zeros: 256 B of zeros (out-of-map taps of the 3x3 convs)
-    float *d_x = nullptr, *d_headout = nullptr, *d_taps = nullptr;
+    // residual stream as a bf16 pair (x = xh + xl), its chunk partial statistics and the row terms of the
+    // folded LayerNorm (vt_common.hpp); folded weights of all layers
+    bf16_t *d_xh = nullptr, *d_xl = nullptr, *d_foldw = nullptr, *d_taps = nullptr;
+    float2 *d_cstat = nullptr, *d_rstat = nullptr;
+    float *d_foldv = nullptr, *d_headout = nullptr;
     StreamState* d_states = nullptr;
     FrameDesc* d_frames = nullptr;
     vt_result* d_results = nullptr;
@@ -203,8 +211,9 @@ void Engine::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    void* devp[] = {d_blob, d_patches, d_ln, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
-                    d_x, d_headout, d_taps, d_states, d_frames, d_results, d_stage};
+    void* devp[] = {d_blob, d_patches, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
+                    d_xh, d_xl, d_cstat, d_rstat, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
+                    d_results, d_stage};
     for (void* p : devp)
         if (p) (void)hipFree(p);
     if (h_frames) (void)hipHostFree(h_frames);
@@ -367,9 +376,11 @@ static hipError_t dalloc0(T** p, size_t count) {
 // HBM the activations of B streams need (bytes), as alloc_buffers() lays them out
 size_t Engine::activation_bytes() const {
     const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
-    return 2 * (M * d.kpad + M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
-                Ms * d.D + 2 * Ms * d.C) +
-           4 * (M * d.D + Ms * 8) + (size_t)B * (sizeof(StreamState) + sizeof(FrameDesc) + sizeof(vt_result));
+    const size_t fold_rows = (size_t)d.L * (3 * d.D + d.mlp);      // folded QKV + fc1 weights of every layer
+    return 2 * (M * d.kpad + 2 * M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
+                Ms * d.D + 2 * Ms * d.C + fold_rows * d.D) +
+           8 * (M * (d.D / VT_STAT_CHUNK) + M) + 4 * (Ms * 8 + 2 * fold_rows) +
+           (size_t)B * (sizeof(StreamState) + sizeof(FrameDesc) + sizeof(vt_result));
 }
 
 int Engine::alloc_buffers() {
@@ -386,8 +397,26 @@ int Engine::alloc_buffers() {
                            "are free on device %d", B, need / 1048576.0, free_b / 1048576.0, device);
     }
     HIPCHK(dalloc0(&d_patches, M * d.kpad));
-    HIPCHK(dalloc0(&d_x, M * d.D));
-    HIPCHK(dalloc0(&d_ln, M * d.D));
+    HIPCHK(dalloc0(&d_xh, M * d.D));
+    HIPCHK(dalloc0(&d_xl, M * d.D));
+    HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK)));
+    HIPCHK(dalloc0(&d_rstat, M));
+    {   // fold LayerNorm 1 / 2 of every layer into the QKV / fc1 weights
+        const size_t rows = (size_t)3 * d.D + d.mlp;
+        HIPCHK(dalloc0(&d_foldw, (size_t)d.L * rows * d.D));
+        HIPCHK(dalloc0(&d_foldv, (size_t)d.L * 2 * rows));
+        for (int l = 0; l < d.L; ++l) {
+            LayerW& w = layers[l];
+            bf16_t* fw = d_foldw + (size_t)l * rows * d.D;
+            float* fv = d_foldv + (size_t)l * 2 * rows;
+            HIPCHK(launch_fold_layernorm(w.qkv_w, w.ln1_g, w.ln1_b, w.qkv_b, fw, fv, fv + rows, 3 * d.D, d.D, stream));
+            HIPCHK(launch_fold_layernorm(w.fc1_w, w.ln2_g, w.ln2_b, w.fc1_b, fw + (size_t)3 * d.D * d.D, fv + 3 * d.D,
+                                         fv + rows + 3 * d.D, d.mlp, d.D, stream));
+            w.qkv_wf = fw; w.qkv_cs = fv; w.qkv_c = fv + rows;
+            w.fc1_wf = fw + (size_t)3 * d.D * d.D; w.fc1_cs = fv + 3 * d.D; w.fc1_c = fv + rows + 3 * d.D;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+    }
     HIPCHK(dalloc0(&d_qk, M * 2 * d.D));
     HIPCHK(dalloc0(&d_vt, (size_t)B * d.H * 64 * d.npad));
     HIPCHK(dalloc0(&d_attn, M * d.D));
@@ -452,40 +481,48 @@ int Engine::run_pass(Profiler* prof) {
     };
     auto gemm = [&](int epi, GemmArgs a) {
         const double fl = 2.0 * a.M * a.N * a.K;
+        // algorithmic bytes: operands once, output once; the residual pair is read and written (4 + 4 B)
         const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
-                          (epi == EPI_RESID || epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
+                          (epi == EPI_RESID ? 8.0 : epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
         L(prof ? gemm_name(epi, a.M, a.N, a.K) : "", fl, by, [&] { return launch_gemm(a, epi, stream); });
     };
     auto tap = [&](int slot) {
-        if (taps && lerr == hipSuccess)
-            lerr = hipMemcpyAsync(d_taps + (size_t)slot * M * D, d_x, sizeof(float) * M * D,
-                                  hipMemcpyDeviceToDevice, stream);
+        if (taps && lerr == hipSuccess) {     // both halves of the residual stream: [slot][hi | lo][M][D]
+            bf16_t* dst = d_taps + (size_t)slot * 2 * M * D;
+            lerr = hipMemcpyAsync(dst, d_xh, sizeof(bf16_t) * M * D, hipMemcpyDeviceToDevice, stream);
+            if (lerr == hipSuccess)
+                lerr = hipMemcpyAsync(dst + (size_t)M * D, d_xl, sizeof(bf16_t) * M * D, hipMemcpyDeviceToDevice, stream);
+        }
+    };
+    const int nchunk = D / VT_STAT_CHUNK;
+    // row terms (rstd, -mean * rstd) of the LayerNorm that follows an X-epilogue, from its chunk partials
+    auto rowstats = [&] {
+        L("rowstat", 0, (double)M * (nchunk + 1) * 8,
+          [&] { return launch_rowstat_finalize(d_cstat, d_rstat, M, nchunk, d.ln_eps, stream); });
     };
 
     // K1: crop + resize + normalise the search window of every stream -> patch rows
     L("preproc_search", 0, (double)B * (d.S * d.S * 3 * 2 + 1.5 * d.S * d.S),
       [&] { return launch_preproc(d_frames, d_states, d_patches, d, 0, B, false, stream); });
-    // K2: patch embedding (+bias +pos) -> f32 residual stream
+    // K2: patch embedding (+bias +pos) -> residual stream (bf16 pair + chunk statistics)
     {
         GemmArgs a{};
         a.A = d_patches; a.lda = d.kpad;
         a.W = (const bf16_t*)find("patch_w")->ptr; a.ldw = d.kpad;
         a.bias = (const float*)find("patch_b")->ptr;
         a.M = M; a.N = D; a.K = d.kpad;
-        a.Cf = d_x; a.ldc = D;
+        a.Xh = d_xh; a.Xl = d_xl; a.ldx = D; a.cstat = d_cstat;
         a.pos = (const float*)find("pos")->ptr; a.pos_rows = d.ntok;
         gemm(EPI_F32_POS, a);
     }
     tap(0);
-    const double ln_bytes = (double)M * D * 6;
     for (int l = 0; l < d.L; ++l) {
         const LayerW& w = layers[l];
-        L("layernorm", 0, ln_bytes, [&] {
-            return launch_layernorm(d_x, w.ln1_g, w.ln1_b, d_ln, M, D, M, 0, 0, d.ln_eps, stream);
-        });
+        rowstats();                         // LayerNorm 1, folded into the QKV GEMM
         {
             GemmArgs a{};
-            a.A = d_ln; a.lda = D; a.W = w.qkv_w; a.ldw = D; a.bias = w.qkv_b;
+            a.A = d_xh; a.lda = D; a.W = w.qkv_wf; a.ldw = D; a.bias = w.qkv_c;
+            a.rowstat = d_rstat; a.colsum = w.qkv_cs;
             a.M = M; a.N = 3 * D; a.K = D;
             a.qk = d_qk; a.vt = d_vt; a.tokens = d.ntok; a.npad = d.npad; a.D = D;
             a.vt_perm = attention_vt_perm(attention_pick_mode(d.ntok, d.npad));   // layout the attention kernel reads
@@ -497,31 +534,31 @@ int Engine::run_pass(Profiler* prof) {
         {
             GemmArgs a{};
             a.A = d_attn; a.lda = D; a.W = w.proj_w; a.ldw = D; a.bias = w.proj_b;
-            a.M = M; a.N = D; a.K = D; a.Cf = d_x; a.ldc = D;
+            a.M = M; a.N = D; a.K = D; a.Xh = d_xh; a.Xl = d_xl; a.ldx = D; a.cstat = d_cstat;
             gemm(EPI_RESID, a);
         }
-        L("layernorm", 0, ln_bytes, [&] {
-            return launch_layernorm(d_x, w.ln2_g, w.ln2_b, d_ln, M, D, M, 0, 0, d.ln_eps, stream);
-        });
+        rowstats();                         // LayerNorm 2, folded into fc1
         {
             GemmArgs a{};
-            a.A = d_ln; a.lda = D; a.W = w.fc1_w; a.ldw = D; a.bias = w.fc1_b;
+            a.A = d_xh; a.lda = D; a.W = w.fc1_wf; a.ldw = D; a.bias = w.fc1_c;
+            a.rowstat = d_rstat; a.colsum = w.fc1_cs;
             a.M = M; a.N = d.mlp; a.K = D; a.Cb = d_mlp; a.ldcb = d.mlp;
             gemm(EPI_GELU_BF16, a);
         }
         {
             GemmArgs a{};
             a.A = d_mlp; a.lda = d.mlp; a.W = w.fc2_w; a.ldw = d.mlp; a.bias = w.fc2_b;
-            a.M = M; a.N = D; a.K = d.mlp; a.Cf = d_x; a.ldc = D;
+            a.M = M; a.N = D; a.K = d.mlp; a.Xh = d_xh; a.Xl = d_xl; a.ldx = D;
+            a.cstat = l + 1 < d.L ? d_cstat : nullptr;      // the final LayerNorm reads the rows itself
             gemm(EPI_RESID, a);
         }
         tap(1 + l);
     }
     // final LayerNorm on the search tokens only, compacted to [B*ns][D]
     L("layernorm", 0, (double)Ms * D * 6, [&] {
-        return launch_layernorm(d_x, (const float*)find("norm_g")->ptr,
-                                (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
-                                d.nt, d.ln_eps, stream);
+        return launch_layernorm_split(d_xh, d_xl, (const float*)find("norm_g")->ptr,
+                                      (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
+                                      d.nt, d.ln_eps, stream);
     });
     // centre head: 1x1 conv, three 3x3 convs (implicit GEMMs), then the f32 5-logit layer + decode
     {
@@ -988,8 +1025,8 @@ int vt_group_enable_taps(vt_group* g, int enable) try {
     Engine* e = g->e;
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (enable && !e->d_taps)
-        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * e->B * e->d.ntok * e->d.D));
+    if (enable && !e->d_taps)      // per slot: the hi and the lo half of the residual stream
+        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * 2 * e->B * e->d.ntok * e->d.D));
     e->taps = enable != 0;
     return VT_OK;
 } VT_NOTHROW_INT
@@ -1061,6 +1098,22 @@ static int64_t copy_out_f32(const float* dsrc, int64_t count, float* out, int64_
         return set_err(VT_ERR_HIP, "read_tensor: copy failed");
     return count;
 }
+// the residual stream: hi + lo in float32 (the value the bf16 pair stands for)
+static int64_t copy_out_pair(const bf16_t* dhi, const bf16_t* dlo, int64_t count, float* out, int64_t cap) {
+    if (!out) return count;
+    if (cap < count) return set_err(VT_ERR_INVALID_ARG, "read_tensor: capacity %lld < %lld", (long long)cap, (long long)count);
+    std::vector<bf16_t> hi((size_t)count), lo((size_t)count);
+    if (hipMemcpy(hi.data(), dhi, 2 * count, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(lo.data(), dlo, 2 * count, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(VT_ERR_HIP, "read_tensor: copy failed");
+    for (int64_t i = 0; i < count; ++i) {
+        const uint32_t uh = ((uint32_t)hi[i]) << 16, ul = ((uint32_t)lo[i]) << 16;
+        float fh, fl;
+        memcpy(&fh, &uh, 4); memcpy(&fl, &ul, 4);
+        out[i] = fh + fl;
+    }
+    return count;
+}
 static int64_t copy_out_bf16(const bf16_t* dsrc, int64_t count, float* out, int64_t cap) {
     if (!out) return count;
     if (cap < count) return set_err(VT_ERR_INVALID_ARG, "read_tensor: capacity %lld < %lld", (long long)cap, (long long)count);
@@ -1089,7 +1142,8 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
     if (n == "attn") return copy_out_bf16(e->d_attn + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
     if (n == "head_t3") return copy_out_bf16(e->d_tb + b * d.ns * d.C, (int64_t)d.ns * d.C, out, capacity);
     if (n == "head_out") return copy_out_f32(e->d_headout + b * d.ns * 8, (int64_t)d.ns * 8, out, capacity);
-    if (n == "x") return copy_out_f32(e->d_x + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
+    if (n == "x") return copy_out_pair(e->d_xh + b * d.ntok * d.D, e->d_xl + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
+    if (n == "rowstat") return copy_out_f32((const float*)(e->d_rstat + b * d.ntok), (int64_t)d.ntok * 2, out, capacity);
     if (n == "state") {
         static_assert(sizeof(StreamState) % 4 == 0, "state size");
         return copy_out_f32((const float*)(e->d_states + b), sizeof(StreamState) / 4, out, capacity);
@@ -1100,7 +1154,8 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
     if (slot >= 0 && slot <= d.L) {
         if (!e->d_taps) return set_err(VT_ERR_INVALID_ARG, "taps not enabled (vt_group_enable_taps)");
         const size_t M = (size_t)e->B * d.ntok;
-        return copy_out_f32(e->d_taps + ((size_t)slot * M + b * d.ntok) * d.D, (int64_t)d.ntok * d.D, out, capacity);
+        const bf16_t* hi = e->d_taps + ((size_t)slot * 2 * M + b * d.ntok) * d.D;
+        return copy_out_pair(hi, hi + M * d.D, (int64_t)d.ntok * d.D, out, capacity);
     }
     return set_err(VT_ERR_INVALID_ARG, "unknown tensor '%s'", name);
 } VT_NOTHROW_INT
@@ -1604,45 +1659,91 @@ int vt_overlay_rgb8(int device_id, uint8_t* rgb, int width, int height, const vt
 
 // ---- operator-level entry points ---------------------------------------------------------------------------
 
+// host-side helpers of the operator entry points: float32 <-> the bf16 pair of the residual stream
+static inline bf16_t host_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float host_f32(bf16_t b) {
+    const uint32_t u = ((uint32_t)b) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// epilogue: 0 x = acc + bias, 1 x = (acc + bias) + c_inout, 4 x = (acc + bias) + pos (pos = c_inout, one
+// row per output row) - the X-epilogues: c_inout goes in and comes back through the bf16 pair (hi + lo, 17
+// significant bits), rowstat_out (if given) receives the finalized row terms (rstd, -mean * rstd) of x;
+// 2 gelu, 3 relu -> bf16, with an optional folded LayerNorm (rowstat_in [M][2], colsum [N]).
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* c_inout,
-                    int M, int N, int K, int epilogue, int cfg) try {
+                    int M, int N, int K, int epilogue, int cfg, const float* rowstat_in, const float* colsum,
+                    float* rowstat_out, float eps) try {
     if (!a || !w || !c_inout || M <= 0 || N <= 0 || K <= 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (N % 64 || K % 64) return set_err(VT_ERR_INVALID_ARG, "gemm: N and K must be multiples of 64");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
-    DevBuf da, dw, db, dc, dcb;
+    const size_t MN = (size_t)M * N;
+    DevBuf da, dw, db, dxh, dxl, dpos, dcb, dcs, drs, dcst, dro;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
-    HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
+    HIPCHK(dxh.alloc(MN * 2)); HIPCHK(dxl.alloc(MN * 2)); HIPCHK(dcb.alloc(MN * 2));
     HIPCHK(hipMemcpy(da.p, a, (size_t)M * K * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
     std::vector<float> zb((size_t)N, 0.0f);
     HIPCHK(hipMemcpy(db.p, bias ? bias : zb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dc.p, c_inout, (size_t)M * N * 4, hipMemcpyHostToDevice));
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
-    g.M = M; g.N = N; g.K = K; g.Cf = (float*)dc.p; g.ldc = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    g.M = M; g.N = N; g.K = K; g.Xh = (bf16_t*)dxh.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
     int epi;
     switch (epilogue) {
         case 0: epi = EPI_F32; break;
         case 1: epi = EPI_RESID; break;
         case 2: epi = EPI_GELU_BF16; break;
         case 3: epi = EPI_RELU_BF16; break;
+        case 4: epi = EPI_F32_POS; break;
         default: return set_err(VT_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
+    }
+    const bool x_epi = epi == EPI_F32 || epi == EPI_RESID || epi == EPI_F32_POS;
+    std::vector<bf16_t> hi, lo;
+    if (epi == EPI_RESID) {
+        hi.resize(MN); lo.resize(MN);
+        for (size_t i = 0; i < MN; ++i) { hi[i] = host_bf16(c_inout[i]); lo[i] = host_bf16(c_inout[i] - host_f32(hi[i])); }
+        HIPCHK(hipMemcpy(dxh.p, hi.data(), MN * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dxl.p, lo.data(), MN * 2, hipMemcpyHostToDevice));
+    } else if (epi == EPI_F32_POS) {
+        HIPCHK(dpos.alloc(MN * 4));
+        HIPCHK(hipMemcpy(dpos.p, c_inout, MN * 4, hipMemcpyHostToDevice));
+        g.pos = (const float*)dpos.p; g.pos_rows = M;
+    }
+    if (x_epi) {
+        HIPCHK(dcst.alloc((size_t)M * (N / VT_STAT_CHUNK) * 8));
+        g.cstat = (float2*)dcst.p;
+    } else if (rowstat_in) {
+        if (!colsum) return set_err(VT_ERR_INVALID_ARG, "gemm: rowstat without colsum");
+        HIPCHK(drs.alloc((size_t)M * 8)); HIPCHK(dcs.alloc((size_t)N * 4));
+        HIPCHK(hipMemcpy(drs.p, rowstat_in, (size_t)M * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)N * 4, hipMemcpyHostToDevice));
+        g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;
     }
     if (cfg < 0) HIPCHK(launch_gemm(g, epi, nullptr));
     else if (launch_gemm_cfg(g, epi, cfg, nullptr) != hipSuccess)
         return set_err(VT_ERR_INVALID_ARG, "gemm: tile configuration %d does not fit M=%d N=%d K=%d", cfg, M, N, K);
+    if (x_epi && rowstat_out) {
+        HIPCHK(dro.alloc((size_t)M * 8));
+        HIPCHK(launch_rowstat_finalize(g.cstat, (float2*)dro.p, M, N / VT_STAT_CHUNK, eps, nullptr));
+    }
     HIPCHK(hipDeviceSynchronize());
-    if (epi == EPI_F32 || epi == EPI_RESID) {
-        HIPCHK(hipMemcpy(c_inout, dc.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (x_epi) {
+        hi.resize(MN); lo.resize(MN);
+        HIPCHK(hipMemcpy(hi.data(), dxh.p, MN * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lo.data(), dxl.p, MN * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < MN; ++i) c_inout[i] = host_f32(hi[i]) + host_f32(lo[i]);
+        if (rowstat_out) HIPCHK(hipMemcpy(rowstat_out, dro.p, (size_t)M * 8, hipMemcpyDeviceToHost));
     } else {
-        std::vector<bf16_t> tmp((size_t)M * N);
+        std::vector<bf16_t> tmp(MN);
         HIPCHK(hipMemcpy(tmp.data(), dcb.p, tmp.size() * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < tmp.size(); ++i) {
-            uint32_t u = ((uint32_t)tmp[i]) << 16;
-            memcpy(c_inout + i, &u, 4);
-        }
+        for (size_t i = 0; i < tmp.size(); ++i) c_inout[i] = host_f32(tmp[i]);
     }
     return VT_OK;
 } VT_NOTHROW_INT
@@ -1656,9 +1757,10 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     DEVICE_SCOPE(device_id);
     HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
     const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 63) / 64 * 64;
-    DevBuf da, dw, db, dc, dcb, dvt;
+    DevBuf da, dw, db, dc, dcb, dvt, dxl, dcst, drs;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
-    HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2));
+    HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2)); HIPCHK(dxl.alloc((size_t)M * N * 2));
+    HIPCHK(dcst.alloc((size_t)M * (N / VT_STAT_CHUNK) * 8)); HIPCHK(drs.alloc((size_t)M * 8));
     HIPCHK(dvt.alloc((size_t)(N / 64 + 1) * 64 * npad * 2));
     std::vector<bf16_t> ha((size_t)M * K), hw((size_t)N * K);
     uint32_t seed = 12345u;
@@ -1669,9 +1771,18 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     HIPCHK(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(db.p, 0, (size_t)N * 4));
     HIPCHK(hipMemset(dc.p, 0, (size_t)M * N * 4));
+    HIPCHK(hipMemset(dcb.p, 0, (size_t)M * N * 2)); HIPCHK(hipMemset(dxl.p, 0, (size_t)M * N * 2));
+    {   // folded-LayerNorm row terms as the engine passes them to the QKV / fc1 GEMMs: (1, 0) per row
+        std::vector<float> rs((size_t)M * 2);
+        for (int i = 0; i < M; ++i) { rs[2 * (size_t)i] = 1.0f; rs[2 * (size_t)i + 1] = 0.0f; }
+        HIPCHK(hipMemcpy(drs.p, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+    }
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
-    g.M = M; g.N = N; g.K = K; g.Cf = (float*)dc.p; g.ldc = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    g.M = M; g.N = N; g.K = K; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    const bool x_epi = epilogue == EPI_F32 || epilogue == EPI_RESID || epilogue == EPI_F32_POS;
+    if (x_epi) { g.Xh = (bf16_t*)dcb.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.cstat = (float2*)dcst.p; }
+    else if (epilogue == EPI_QKV || epilogue == EPI_GELU_BF16) { g.rowstat = (const float2*)drs.p; g.colsum = (const float*)db.p; }
     g.pos = (const float*)dc.p; g.pos_rows = M;
     g.qk = (bf16_t*)dcb.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
     if (epilogue == EPI_QKV && (N % 192 || tokens != M)) return set_err(VT_ERR_INVALID_ARG, "qkv bench: N = 3D, D % 64 == 0, M % 4 == 0");
@@ -1710,7 +1821,8 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
 } VT_NOTHROW_INT
 
 int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* qk_out,
-                   float* vt_out, int B, int tokens, int D, int cfg, int vt_perm) try {
+                   float* vt_out, int B, int tokens, int D, int cfg, int vt_perm, const float* rowstat_in,
+                   const float* colsum) try {
     // QKV GEMM with the attention-layout epilogue: qk_out [B*tokens][2D], vt_out [B*H][64][npad]
     if (!a || !w || !bias || !qk_out || !vt_out || B <= 0 || tokens <= 0 || D % 64 || (tokens & 3))
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
@@ -1729,6 +1841,14 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     g.A = (const bf16_t*)da.p; g.lda = D; g.W = (const bf16_t*)dw.p; g.ldw = D; g.bias = (const float*)db.p;
     g.M = M; g.N = 3 * D; g.K = D; g.qk = (bf16_t*)dqk.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
     g.vt_perm = vt_perm ? 1 : 0;   // 1: the key order attention mode 3 reads
+    DevBuf drs, dcs;
+    if (rowstat_in) {              // folded LayerNorm: [M][2] row terms, [3D] column sums
+        if (!colsum) return set_err(VT_ERR_INVALID_ARG, "qkv: rowstat without colsum");
+        HIPCHK(drs.alloc((size_t)M * 8)); HIPCHK(dcs.alloc((size_t)3 * D * 4));
+        HIPCHK(hipMemcpy(drs.p, rowstat_in, (size_t)M * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)3 * D * 4, hipMemcpyHostToDevice));
+        g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;
+    }
     if (cfg < 0) HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
     else if (launch_gemm_cfg(g, EPI_QKV, cfg, nullptr) != hipSuccess)
         return set_err(VT_ERR_INVALID_ARG, "qkv: tile configuration %d does not fit this shape", cfg);

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 2   /* 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
+#define VT_ABI_VERSION 3   /* 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
 
 typedef enum vt_status {
     VT_OK = 0,
@@ -341,7 +341,8 @@ int vt_group_set_state_box(vt_group* g, int stream, const float* box4);
 
 /* Copy an intermediate tensor of the last pass to the host as float32.
  * names: "patches" [N,Kpad], "tokens0" [N,D], "layer<i>" [N,D] (residual stream after block i;
- * both need taps), "x" [N,D] (final residual stream), "attn" [N,D] (last block's attention output),
+ * both need taps), "x" [N,D] (final residual stream; like the taps the sum of the bf16 pair it is stored
+ * as), "rowstat" [N,2] (row terms of the last folded LayerNorm), "attn" [N,D] (last block's attention output),
  * "feat" [Ns,D], "head_t3" [Ns,C], "head_out" [Ns,8] (score,ox,oy,w,h logits),
  * "state" (the stream's device state record as raw 32-bit words).
  * Returns the element count, or a negative vt_status. With out == NULL only the count. */
@@ -350,12 +351,21 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
 
 /* ---- operator-level entry points (numerics tests call the same kernels the pass uses) ---- */
 
-/* C[M,N] (f32) = A[M,K] (bf16 bits) x W[N,K]^T (bf16 bits) + bias[N]; epilogue:
- * 0 = f32 store, 1 = C += (residual), 2 = GELU -> bf16 (returned widened to f32),
- * 3 = ReLU -> bf16 (widened). Host pointers. K % 64 == 0, N % 64 == 0. cfg: tile configuration as
- * in vt_op_gemm_bench (< 0: the launcher's own choice for the shape). */
+/* acc[M,N] = A[M,K] (bf16 bits) x W[N,K]^T (bf16 bits), float32 accumulation. Host pointers.
+ * K % 64 == 0, N % 64 == 0. cfg: tile configuration as in vt_op_gemm_bench (< 0: the launcher's own
+ * choice for the shape). epilogue:
+ *   0  x = acc + bias                    the X-epilogues the engine keeps its residual stream with: x is
+ *   1  x = (acc + bias) + c_inout        stored as a bf16 pair (hi = bf16(x), lo = bf16(x - hi)) and comes
+ *   4  x = (acc + bias) + pos            back as hi + lo (17 significant bits); pos = c_inout, one row per
+ *                                        output row. rowstat_out (may be NULL) receives per row the terms
+ *                                        (rstd, -mean * rstd) of LayerNorm(x) with `eps`, computed from the
+ *                                        float32 x before the split (what the consuming GEMM multiplies with).
+ *   2  GELU(y) -> bf16, 3  ReLU(y) -> bf16 (returned widened to f32); y = acc + bias, or with a folded
+ *      LayerNorm (rowstat_in [M][2] and colsum [N] not NULL): y = rowstat_in[m][0] * acc +
+ *      (rowstat_in[m][1] * colsum[n] + bias[n]). */
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                    float* c_inout, int M, int N, int K, int epilogue, int cfg);
+                    float* c_inout, int M, int N, int K, int epilogue, int cfg,
+                    const float* rowstat_in, const float* colsum, float* rowstat_out, float eps);
 /* Kernel-tuning helper: mean microseconds per launch of the GEMM kernel on device-resident random
  * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
  * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2
@@ -371,9 +381,11 @@ int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w,
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
  * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;
- * vt_perm = 1: Vt in the key order attention mode 3 reads (attn_perm16 inside every 16 keys). */
+ * vt_perm = 1: Vt in the key order attention mode 3 reads (attn_perm16 inside every 16 keys).
+ * rowstat_in [B*tokens][2] / colsum [3D] (both or neither NULL): a folded LayerNorm as in vt_op_gemm_bf16. */
 int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                   float* qk_out, float* vt_out, int B, int tokens, int D, int cfg, int vt_perm);
+                   float* qk_out, float* vt_out, int B, int tokens, int D, int cfg, int vt_perm,
+                   const float* rowstat_in, const float* colsum);
 /* out[B,N,H*64] (bf16 widened to f32) = softmax(q k^T) v per head; q,k,v: [B,N,H*64] bf16 bits
  * (q already scaled). mode as in vt_op_attention_bench. */
 int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v,

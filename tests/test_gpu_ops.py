@@ -410,3 +410,103 @@ def test_gemm256_persistent_qkv_and_activation_full_chip(gpu, tokens, B):
     ref = bf16_round(np.maximum(z, 0))
     for _ in range(3):
         assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=19), ref)
+
+
+# ---- the split residual stream and the folded LayerNorm (numerical spec v2) -------
+
+def _split_pair(x):
+    """float32 -> hi + lo as the engine stores the residual stream (two bf16 roundings)"""
+    x = np.asarray(x, np.float32)
+    hi = bf16_round(x)
+    return hi + bf16_round(x - hi)
+
+
+def _row_terms(x, eps=1e-6):
+    x = x.astype(np.float64)
+    mean = x.mean(axis=1)
+    rstd = 1.0 / np.sqrt(x.var(axis=1) + eps)
+    return np.stack([rstd, -mean * rstd], axis=1)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18])
+@pytest.mark.parametrize("epi", [0, 1, 4])
+def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
+    """the three epilogues that write the residual stream (0 plain, 1 += old pair, 4 += positional rows):
+    the value comes back as the bf16 pair of the float32 result, and the finalized row terms of the
+    LayerNorm that follows equal NumPy's (float64) on that float32 result - on a ragged M, every tile
+    configuration, a row mean that is NOT small against the spread (chunk-wise combination must not
+    cancel)"""
+    rng = np.random.default_rng(cfg * 10 + epi)
+    M, N, K = 720 + 37, 768, (512 if cfg in (4, 5, 6) else 384)
+    ab, a = _rand_bf16(gpu, rng, (M, K))
+    wb, w = _rand_bf16(gpu, rng, (N, K), 0.05)
+    bias = (rng.standard_normal(N) + 3.0).astype(np.float32)          # mean ~ 3, spread ~ 1.5
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    z = a @ w.T + bias
+    v = z if epi == 0 else (z + (_split_pair(c0) if epi == 1 else c0)).astype(np.float32)
+    got, rs = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=epi, cfg=cfg, want_rowstat=True)
+    assert np.abs(got - v).max() < 2e-3                                # accumulation order
+    assert np.all(np.abs(got - _split_pair(got)) == 0)                 # it IS a bf16 pair
+    ref = _row_terms(v)
+    assert np.abs(rs[:, 0] / ref[:, 0] - 1).max() < 2e-5, np.abs(rs[:, 0] / ref[:, 0] - 1).max()
+    assert np.abs(rs[:, 1] - ref[:, 1]).max() < 2e-4 * np.abs(ref[:, 1]).max()
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 17, 18])
+def test_x_epilogues_exact_integers(gpu, cfg):
+    """small-integer operands: every sum is exact and fits the 16 significant bits of the pair, so the
+    X-epilogues must return the exact integers (a mis-staged row, a swapped hi / lo or a wrong addend
+    row is a wrong integer), the positional variant with a period shorter than M included"""
+    rng = np.random.default_rng(cfg)
+    M, N, K = 517, 256, 256
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
+    ref = a @ w.T + bias
+    ab, wb = _bits(gpu, a), _bits(gpu, w)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg), ref)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=1, cfg=cfg), ref + c0)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=4, cfg=cfg), ref + c0)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
+@pytest.mark.parametrize("epi", [2, 3])
+def test_folded_layernorm_in_the_bf16_epilogues(gpu, cfg, epi):
+    """y = rowstat[m][0] * acc + (rowstat[m][1] * colsum[n] + bias[n]) ahead of GELU / ReLU: integer
+    operands and integer row / column terms make y an exact integer (ReLU: the bf16 of it, exactly);
+    config 19 at a size that takes the persistent kernel (more tiles than CUs)"""
+    rng = np.random.default_rng(cfg * 7 + epi)
+    M, N, K = (300 * 71, 3072, 256) if cfg == 19 else (720 + 37, 768, 256)
+    a = rng.integers(-3, 4, size=(M, K)).astype(np.float32)
+    w = rng.integers(-3, 4, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    rs = np.stack([rng.integers(1, 4, size=M), rng.integers(-2, 3, size=M)], axis=1).astype(np.float32)
+    cs = rng.integers(-5, 6, size=N).astype(np.float32)
+    y = rs[:, :1] * (a @ w.T) + (rs[:, 1:] * cs[None, :] + bias[None, :])
+    got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=epi, cfg=cfg, rowstat=rs, colsum=cs)
+    if epi == 3:
+        assert np.array_equal(got, bf16_round(np.maximum(y, 0)))
+    else:
+        ref = 0.5 * y * (1.0 + erf(y * 0.7071067811865476))
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 5, 17, 18, 19])
+def test_folded_layernorm_in_the_qkv_epilogue(gpu, cfg):
+    """the same row / column terms through the QKV epilogue: q (scaled), k row-major and V transposed
+    (the V tiles read the row terms per register, not per lane)"""
+    rng = np.random.default_rng(cfg)
+    B, tokens, D = (71, 300, 768) if cfg == 19 else (2, 100, 768)
+    M = B * tokens
+    a = rng.integers(-3, 4, size=(M, D)).astype(np.float32)
+    w = rng.integers(-3, 4, size=(3 * D, D)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=3 * D).astype(np.float32)
+    rs = np.stack([rng.integers(1, 3, size=M), rng.integers(-2, 3, size=M)], axis=1).astype(np.float32)
+    cs = rng.integers(-5, 6, size=3 * D).astype(np.float32)
+    z = rs[:, :1] * (a @ w.T) + (rs[:, 1:] * cs[None, :] + bias[None, :])      # exact integers
+    qk, vt_ = gpu.op_qkv_bf16(_bits(gpu, a), _bits(gpu, w), bias, B, tokens, D, cfg=cfg, rowstat=rs, colsum=cs)
+    ref_qk = np.concatenate([bf16_round(z[:, :D] * QK_SCALE), bf16_round(z[:, D:2 * D])], axis=1)
+    assert np.array_equal(qk, ref_qk)
+    v = bf16_round(z[:, 2 * D:]).reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
+    assert np.array_equal(vt_[:, :, :tokens], v)

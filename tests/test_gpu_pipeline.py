@@ -94,6 +94,13 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+# residual stream (max over blocks), final features, head logits: relative to the tensor's maximum
+# measured (round 3, spec v2): tiny 1.2e-4 / 2.3e-3 / 1.0e-3, cfg2 1.2e-3 / 4.0e-3 / 4.4e-3,
+# cfg3 1.1e-3 / 3.9e-3 / 5.3e-3, cfg5 2.1e-3 / 4.1e-3 / 5.2e-3
+TAP_BARS = {"tiny": (5e-4, 6e-3, 3e-3), "cfg2": (3e-3, 8e-3, 1e-2), "cfg3": (3e-3, 8e-3, 1.2e-2),
+            "cfg5": (5e-3, 9e-3, 1.2e-2)}
+
+
 @pytest.mark.parametrize("cfg", ["tiny", "cfg2", "cfg3", "cfg5"])
 def test_network_stage_taps(gpu, oracle, cfg):
     """residual stream after the patch embedding and after EVERY encoder block, final features and
@@ -118,15 +125,20 @@ def test_network_stage_taps(gpu, oracle, cfg):
     assert np.array_equal(g.read_tensor("patches").reshape(n, mi.kpad),
                           oracle.bf16_bits_to_f32(ref.last["patches"]))
     tok0 = g.read_tensor("tokens0").reshape(n, d)
-    assert _rel(tok0, ref.last["tokens0"]) < 1e-5
-    for l in range(mi.layers):
-        x = g.read_tensor(f"layer{l}").reshape(n, d)
-        assert _rel(x, ref.last[f"layer{l}"]) < 2e-2, f"layer {l}"
+    assert _rel(tok0, ref.last["tokens0"]) < 2e-5
+    # bars = 2-3 x what was measured (tools/arbiter.py): both implementations round
+    # to bf16 at the same points, what differs is float32 summation order, so a one-ulp bf16 flip here and
+    # there is all there is - a kernel that makes the stream ten times worse must fail
+    bar_x, bar_feat, bar_head = TAP_BARS[cfg]
+    worst = max(_rel(g.read_tensor(f"layer{l}").reshape(n, d), ref.last[f"layer{l}"]) for l in range(mi.layers))
     feat = g.read_tensor("feat").reshape(mi.tokens_search, d)
-    assert _rel(feat, ref.last["feat"]) < 3e-2
     ho = g.read_tensor("head_out").reshape(mi.tokens_search, 8)
-    assert np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() < 0.05 * max(
-        1.0, np.abs(ref.last["head_out"]).max())
+    e_head = np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() / max(1.0, np.abs(ref.last["head_out"]).max())
+    print(f"\n[taps {cfg}] residual worst layer {worst:.2e} (bar {bar_x:.0e}), feat {_rel(feat, ref.last['feat']):.2e} "
+          f"(bar {bar_feat:.0e}), head logits {e_head:.2e} of max (bar {bar_head:.0e})")
+    assert worst < bar_x
+    assert _rel(feat, ref.last["feat"]) < bar_feat
+    assert e_head < bar_head
     assert abs(r_gpu.score - r_ref.score) < 0.02
     g.enable_taps(False)
 
@@ -153,12 +165,13 @@ def test_network_stage_taps_on_the_30_stream_engine(gpu, oracle, weights_cfg3):
     for i in (0, B - 1):
         assert np.array_equal(grp.read_tensor("patches", i).reshape(n, mi.kpad),
                               oracle.bf16_bits_to_f32(ref.last["patches"]))
-        assert _rel(grp.read_tensor("tokens0", i).reshape(n, d), ref.last["tokens0"]) < 1e-5
+        assert _rel(grp.read_tensor("tokens0", i).reshape(n, d), ref.last["tokens0"]) < 2e-5
+        bar_x, bar_feat, bar_head = TAP_BARS["cfg3"]
         for l in range(mi.layers):
-            assert _rel(grp.read_tensor(f"layer{l}", i).reshape(n, d), ref.last[f"layer{l}"]) < 2e-2, (i, l)
-        assert _rel(grp.read_tensor("feat", i).reshape(mi.tokens_search, d), ref.last["feat"]) < 3e-2
+            assert _rel(grp.read_tensor(f"layer{l}", i).reshape(n, d), ref.last[f"layer{l}"]) < bar_x, (i, l)
+        assert _rel(grp.read_tensor("feat", i).reshape(mi.tokens_search, d), ref.last["feat"]) < bar_feat
         ho = grp.read_tensor("head_out", i).reshape(mi.tokens_search, 8)
-        assert np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() < 0.05 * max(1.0, np.abs(ref.last["head_out"]).max())
+        assert np.abs(ho[:, :5] - ref.last["head_out"][:, :5]).max() < bar_head * max(1.0, np.abs(ref.last["head_out"]).max())
         assert abs(res[i].score - r_ref.score) < 0.02 and np.abs(np.array(res[i].bbox) - np.array(r_ref.bbox)).max() <= 1
 
 
