@@ -104,7 +104,7 @@ def main():
     cfg_name, wl_text = WORKLOADS[args.workload]
     G = args.groups
     # default: every engine gets the batch that fills the 256 CUs in whole GEMM rounds (30 for cfg3)
-    B = args.streams if args.streams > 0 else G * vt.weights.recommended_streams(cfg_name)
+    B = args.streams if args.streams > 0 else G * vt.recommended_streams(vt.model_info_for(cfg_name))
     K, W, R = args.steps, args.warmup, args.ring
     fw, fh, sq = (3840, 2160, 160) if args.workload == "cfg5" else \
         ((640, 480, 64) if args.workload == "tiny" else (1920, 1080, 64))
@@ -114,7 +114,7 @@ def main():
     if args.engines == "auto":
         if args.streams <= 0:
             raise SystemExit("--engines auto needs --streams")
-        sizes = vt.weights.plan_engines(cfg_name, args.streams)
+        sizes = vt.plan_engines(vt.model_info_for(cfg_name), args.streams)      # the C ABI's vt_plan_engines
     elif args.engines:
         sizes = [int(x) for x in args.engines.split("+")]
     else:

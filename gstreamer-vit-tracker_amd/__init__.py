@@ -200,10 +200,20 @@ def recommended_streams(info: "CModelInfo", max_streams: int = 128) -> int:
     return lib().vt_recommended_streams(byref(info), max_streams)
 
 
+def model_info_for(cfg_name: str) -> "CModelInfo":
+    """the fields of vt_model_info the planners read, from a named configuration (no engine needed)"""
+    cfg = weights.get_config(cfg_name)
+    mi = CModelInfo()
+    mi.patch, mi.template_size, mi.search_size = cfg.patch, cfg.template, cfg.search
+    mi.dim, mi.heads, mi.layers, mi.mlp_dim, mi.head_channels = cfg.dim, cfg.heads, cfg.layers, cfg.mlp_dim, cfg.head_ch
+    mi.tokens_template, mi.tokens_search, mi.kpad, mi.score_grid = cfg.n_t, cfg.n_s, cfg.kpad, cfg.grid_s
+    return mi
+
+
 def plan_engines(info: "CModelInfo", n_streams: int) -> list:
     """vt_plan_engines: engine (Group) sizes for n_streams on one GPU that avoid a nearly empty GEMM round"""
-    sizes = (c_int * 8)()
-    k = lib().vt_plan_engines(byref(info), n_streams, sizes, 8)
+    sizes = (c_int * 16)()
+    k = lib().vt_plan_engines(byref(info), n_streams, sizes, 16)
     if k <= 0:
         raise ValueError(f"vt_plan_engines({n_streams}) failed")
     return [int(sizes[i]) for i in range(k)]

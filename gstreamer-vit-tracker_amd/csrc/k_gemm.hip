@@ -439,6 +439,18 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BM * 2 + 16;
             const int heads = p.D >> 6;
+            // folded LayerNorm: the row terms of the 16 rows per 32-row block this lane's registers hold,
+            // fetched once (not per column group); rows past M read the last row, never stored
+            float2 vrs[TM][4][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = m0 + wr * WM + i * 32 + 8 * q + 4 * half + e;
+                        vrs[i][q][e] = p.rowstat ? p.rowstat[m < p.M ? m : p.M - 1] : make_float2(1.0f, 0.0f);
+                    }
             if constexpr (FITS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -452,11 +464,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
                         const int mr = wr * WM + i * 32 + 8 * q + 4 * half;
                         float y[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {      // rows mr .. mr+3 (tokens), this lane's column d
-                            float2 rs = make_float2(1.0f, 0.0f);
-                            if (ln) rs = p.rowstat[m0 + mr + e < p.M ? m0 + mr + e : p.M - 1];
-                            y[e] = __builtin_fmaf(rs.x, acc[i][j][4 * q + e], __builtin_fmaf(rs.y, cs, bias));
-                        }
+                        for (int e = 0; e < 4; ++e)       // rows mr .. mr+3 (tokens), this lane's column d
+                            y[e] = __builtin_fmaf(vrs[i][q][e].x, acc[i][j][4 * q + e], __builtin_fmaf(vrs[i][q][e].y, cs, bias));
                         // permuted Vt layout (attention mode 3): the 4-token run moves inside its
                         // group of 16. Streams on 16-token boundaries: permute the tile-local index
                         // here; otherwise (e.g. 980 tokens) each run is placed by its own stream's
@@ -579,19 +588,18 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 // Chosen from sweeps on MI355X over the tracker's shapes (M = 720 * streams; profiles/
 // gemm_sweep_r01.txt).
-int gemm_pick_config(int M, int N, int K, int epilogue) {
+int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
     const long tiles128 = (long)((M + 127) / 128) * (N / 128);
     const bool n128 = (N % 128) == 0;
     // 256x256 8-wave kernel (k_gemm256.hip): one workgroup per CU, so it wants the grid to fill
     // the 256 CUs in whole rounds; measured against 128x128 on the tracker's shapes it wins from
-    // about half a round upwards unless the last round is nearly empty (profiles/gemm_sweep_r01.txt)
-    if ((N % 256) == 0 && K >= 128) {
-        const long t = (long)((M + 255) / 256) * (N / 256), rounds = (t + 255) / 256;
-        // 19 = schedule v2 with persistent workgroups where that applies (bf16 outputs, more tiles
-        // than CUs), else the one-tile-per-workgroup launch of the same schedule (= 18)
-        // (a last round that is nearly empty still beats the 128x128 kernel: fc2 at 31 streams, 264
-        // tiles = 2 rounds, 133 us against ~160)
-        (void)rounds;
+    // about half a round upwards, also when the last round is nearly empty (fc2 at 31 streams, 264
+    // tiles = 2 rounds: 133 us against ~160; profiles/gemm_sweep_r01.txt). 19 = schedule v2 with
+    // persistent workgroups where that applies (bf16 outputs, more tiles than CUs), else the
+    // one-tile-per-workgroup launch of the same schedule (= 18). Implicit convolutions (the head's
+    // 3x3 layers) gather their A rows in the 4-wave kernel only.
+    if (!conv && (N % 256) == 0 && K >= 128) {
+        const long t = (long)((M + 255) / 256) * (N / 256);
         if (t >= 128) return GEMM_CFG_256PP;
     }
     // Below that the 4-wave kernel (round-2 sweep at 1-8 streams, profiles/r02_small_batch_gemm_ab.txt):
@@ -667,9 +675,16 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
     }
 }
 
+int gemm_effective_config(const GemmArgs& a, int epilogue) {
+    const int cfg = gemm_pick_config(a.M, a.N, a.K, epilogue, a.conv_grid > 0);
+    if (cfg >= GEMM_CFG_256P8 && !gemm256_fits(a, epilogue))       // e.g. an operand beyond 4 GiB
+        return (a.N % 128 == 0 && a.M >= 2048) ? 3 : 2;
+    return cfg;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {
-    int cfg = gemm_pick_config(a.M, a.N, a.K, epilogue);
+    const int cfg = gemm_effective_config(a, epilogue);
     hipError_t e = launch_gemm_cfg(a, epilogue, cfg, st);
-    if (e == hipErrorInvalidValue && cfg != 2) e = launch_gemm_cfg(a, epilogue, 2, st);  // shape does not fit the forced tile
+    if (e == hipErrorInvalidValue && cfg != 2) e = launch_gemm_cfg(a, epilogue, 2, st);  // shape does not fit the chosen tile
     return e;
 }

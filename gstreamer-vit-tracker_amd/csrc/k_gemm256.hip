@@ -83,6 +83,10 @@ template <int OFF>
 __device__ __forceinline__ void lds_read128_asm(u32x4_t& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read64_asm(unsigned long long& dst, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void lds_wait2_asm(u32x4_t& a, u32x4_t& b) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
 }
@@ -157,11 +161,11 @@ __device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int
     auto a_off = [&](int i, int g) -> uint32_t {
         int gm = m0 + g * 128 + i * 64 + srow;
         gm = gm < p.M ? gm : p.M - 1;   // rows past M read the last row; never stored
-        return (uint32_t)((gm * p.lda + schunk * 8) * 2);
+        return (uint32_t)(((size_t)gm * p.lda + schunk * 8) * 2);      // < 2^32: launch_gemm256
     };
     auto b_off = [&](int j, int g) -> uint32_t {
         const int gn = n0 + (g * 2 + (srow >> 5)) * 64 + j * 32 + (srow & 31);
-        return (uint32_t)((gn * p.ldw + schunk * 8) * 2);
+        return (uint32_t)(((size_t)gn * p.ldw + schunk * 8) * 2);
     };
     const uint32_t aoff00 = a_off(0, 0), aoff01 = a_off(0, 1), aoff10 = a_off(1, 0), aoff11 = a_off(1, 1);
     const uint32_t boff00 = b_off(0, 0), boff01 = b_off(0, 1), boff10 = b_off(1, 0), boff11 = b_off(1, 1);
@@ -301,11 +305,11 @@ __device__ __forceinline__ void g256_mainloop2(const GemmArgs& p, char* smem, in
     auto a_off = [&](int i, int g) -> uint32_t {
         int gm = m0 + g * 128 + i * 64 + srow;
         gm = gm < p.M ? gm : p.M - 1;   // rows past M read the last row; never stored
-        return (uint32_t)((gm * p.lda + schunk * 8) * 2);
+        return (uint32_t)(((size_t)gm * p.lda + schunk * 8) * 2);      // < 2^32: launch_gemm256
     };
     auto b_off = [&](int j, int g) -> uint32_t {
         const int gn = n0 + (g * 2 + (srow >> 5)) * 64 + j * 32 + (srow & 31);
-        return (uint32_t)((gn * p.ldw + schunk * 8) * 2);
+        return (uint32_t)(((size_t)gn * p.ldw + schunk * 8) * 2);
     };
     const uint32_t aoff00 = a_off(0, 0), aoff01 = a_off(0, 1), aoff10 = a_off(1, 0), aoff11 = a_off(1, 1);
     const uint32_t boff00 = b_off(0, 0), boff01 = b_off(0, 1), boff10 = b_off(1, 0), boff11 = b_off(1, 1);
@@ -578,33 +582,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             if constexpr (VER == 2) g256_mainloop2<false>(p, smem, m0, n0, acc);
             else g256_mainloop<false>(p, smem, m0, n0, acc);
             const int heads = p.D >> 6;
-            __syncthreads();
+            const bool ln = p.rowstat != nullptr;
+            float bias_[2][2], cs_[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const int drow = wc * 64 + j * 32 + nf * 16 + l15;
-                    const bool ln = p.rowstat != nullptr;
-                    const float bias = p.bias[n0 + drow], cs = ln ? p.colsum[n0 + drow] : 0.0f;
+                    bias_[j][nf] = p.bias[n0 + drow];
+                    cs_[j][nf] = ln ? p.colsum[n0 + drow] : 0.0f;
+                }
+            __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int mf = 0; mf < 4; ++mf) {
-                            // 4-token run q of the 16-token group: runs 1 and 2 swap places in
-                            // the permuted layout (attn_perm16)
-                            // (only when streams start on 16-token boundaries; otherwise the
-                            // runs are placed one by one in the read-out below)
-                            const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
-                            const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
+                for (int mf = 0; mf < 4; ++mf) {
+                    // folded LayerNorm: row terms of tokens 4q .. 4q+3 of this 16-row block, fetched once
+                    // per block (not per column group); rows past M read the last row, never stored
+                    float2 rs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int mrow = m0 + wr * 128 + i * 64 + mf * 16 + 4 * q + e;
+                        rs[e] = ln ? p.rowstat[mrow < p.M ? mrow : p.M - 1] : make_float2(1.0f, 0.0f);
+                    }
+                    // 4-token run q of the 16-token group: runs 1 and 2 swap places in the permuted
+                    // layout (attn_perm16) (only when streams start on 16-token boundaries; otherwise
+                    // the runs are placed one by one in the read-out below)
+                    const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
+                    const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const int drow = wc * 64 + j * 32 + nf * 16 + l15;
                             const f32x4_t a = acc[i][mf][j][nf];
                             float y[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {     // tokens 4q .. 4q+3 of this 16-row block
-                                const int mrow = m0 + wr * 128 + i * 64 + mf * 16 + 4 * q + e;
-                                float2 rs = make_float2(1.0f, 0.0f);
-                                if (ln) rs = p.rowstat[mrow < p.M ? mrow : p.M - 1];
-                                y[e] = __builtin_fmaf(rs.x, a[e], __builtin_fmaf(rs.y, cs, bias));
-                            }
+                            for (int e = 0; e < 4; ++e)
+                                y[e] = __builtin_fmaf(rs[e].x, a[e], __builtin_fmaf(rs[e].y, cs_[j][nf], bias_[j][nf]));
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
                                 make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
                         }
@@ -695,15 +710,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         int r0_ = (M0) + srow, r1_ = (M0) + 128 + srow, r2_ = (M0) + 64 + srow, r3_ = (M0) + 192 + srow; \
         r0_ = r0_ < p.M ? r0_ : p.M - 1; r1_ = r1_ < p.M ? r1_ : p.M - 1;                        \
         r2_ = r2_ < p.M ? r2_ : p.M - 1; r3_ = r3_ < p.M ? r3_ : p.M - 1;                        \
-        aoff00 = (uint32_t)((r0_ * p.lda + schunk * 8) * 2);                                     \
-        aoff01 = (uint32_t)((r1_ * p.lda + schunk * 8) * 2);                                     \
-        aoff10 = (uint32_t)((r2_ * p.lda + schunk * 8) * 2);                                     \
-        aoff11 = (uint32_t)((r3_ * p.lda + schunk * 8) * 2);                                     \
+        aoff00 = (uint32_t)(((size_t)r0_ * p.lda + schunk * 8) * 2);                                     \
+        aoff01 = (uint32_t)(((size_t)r1_ * p.lda + schunk * 8) * 2);                                     \
+        aoff10 = (uint32_t)(((size_t)r2_ * p.lda + schunk * 8) * 2);                                     \
+        aoff11 = (uint32_t)(((size_t)r3_ * p.lda + schunk * 8) * 2);                                     \
         const int bn_ = (N0) + (srow >> 5) * 64 + (srow & 31);                                   \
-        boff00 = (uint32_t)(((bn_) * p.ldw + schunk * 8) * 2);                                   \
-        boff01 = (uint32_t)(((bn_ + 128) * p.ldw + schunk * 8) * 2);                             \
-        boff10 = (uint32_t)(((bn_ + 32) * p.ldw + schunk * 8) * 2);                              \
-        boff11 = (uint32_t)(((bn_ + 160) * p.ldw + schunk * 8) * 2);                             \
+        boff00 = (uint32_t)((((size_t)(bn_)) * p.ldw + schunk * 8) * 2);                                   \
+        boff01 = (uint32_t)((((size_t)(bn_ + 128)) * p.ldw + schunk * 8) * 2);                             \
+        boff10 = (uint32_t)((((size_t)(bn_ + 32)) * p.ldw + schunk * 8) * 2);                              \
+        boff11 = (uint32_t)((((size_t)(bn_ + 160)) * p.ldw + schunk * 8) * 2);                             \
     }
 #define G256P_PROLOGUE()                   \
     G256_STAGE_B(0, 0, 0)                  \
@@ -749,6 +764,31 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         if constexpr (EPI == EPI_QKV) {
             v_tile = n0 >= 2 * p.D;
             scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;
+        }
+        // ---- this tile's epilogue terms, by LDS-DMA into the wave's own staging area (idle until the
+        // epilogue): [0, 1 KiB) the folded LayerNorm's row terms of the wave's 128 rows (float2 each),
+        // [1 KiB, 2 KiB) the bias and [2 KiB, 3 KiB) the column sums of its 64 columns (256 B, four
+        // copies each: every lane fetches, one source array per instruction - a per-lane choice between
+        // two arrays makes hipcc loop over the distinct base pointers, and the lanes it masks off in
+        // each round still write their LDS slots). Fetched with ordinary loads at the epilogue's top
+        // they cost every tile an exposed round trip to wherever the previous kernel left the row terms
+        // (measured: QKV 67 -> 84 us). Up to three more entries at the head of this tile's part of the
+        // vector-memory queue: the counted waits of the main loop then wait for up to three operations
+        // more than they need (always safe; they still never wait for a piece issued after the one they
+        // guard); the data has landed long before the loop's last wait (vmcnt(0)), only this wave reads it.
+        const bool ln = p.rowstat != nullptr;      // launch_persistent: M is even when it is set
+        {
+            int te = tid;
+            asm volatile("" : "+v"(te));           // lane-derived addresses rebuilt per tile (see the epilogue)
+            const int el = te & 63;
+            char* ow = smem + G256P_STAGE + wave * 4096;
+            if (ln) {
+                int r = m0 + wr * 128 + 2 * el;
+                r = r < p.M - 1 ? r : p.M - 2;
+                glds16(reinterpret_cast<const char*>(p.rowstat) + (size_t)r * 8, ow);
+            }
+            glds16(p.bias + n0 + wc * 64 + 4 * (el & 15), ow + 1024);
+            if (ln) glds16(p.colsum + n0 + wc * 64 + 4 * (el & 15), ow + 2048);
         }
         // ---- main loop (schedule v2); its prologue was issued before the previous tile's epilogue.
         // The counted waits below assume only LDS-DMA in the queue; stores of the previous epilogue
@@ -855,27 +895,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
             asm volatile("" : "+v"(te));
             const int el = te & 63, e15 = el & 15, eq = el >> 4;
             // folded LayerNorm (vt_common.hpp): y = a_r * acc + (b_r * colsum[n] + bias[n]); the row terms of
-            // the lane's eight rows (one per 16-row block) and the column sums are fetched here, where the
-            // vector-memory queue is empty (the main loop's last wait was vmcnt(0)): the compiler's wait for
-            // them drains nothing else. Without a LayerNorm a_r = 1, b_r = 0: fma(1, acc, bias) = acc + bias.
-            const bool ln = p.rowstat != nullptr;
+            // the lane's eight rows (one per 16-row block), the bias and the column sums come from the
+            // wave's staging area, where the DMA of the tile's top left them (inline-asm LDS reads, one
+            // wait naming every destination: compiler-visible reads would be sunk into the pipelined
+            // blocks below, each behind a vmcnt(0)). Without a LayerNorm a_r = 1, b_r = 0:
+            // fma(1, acc, bias) = acc + bias.
+            char* ow = smem + G256P_STAGE + wave * 4096;
+            u32x4_t tb[2][2], tc[2][2];
+            unsigned long long tr[8];
+            {
+                const uint32_t a0 = lds_addr(ow) + 1024 + eq * 16, r0 = lds_addr(ow) + e15 * 8;
+                lds_read128_asm<0>(tb[0][0], a0); lds_read128_asm<64>(tb[0][1], a0);
+                lds_read128_asm<128>(tb[1][0], a0); lds_read128_asm<192>(tb[1][1], a0);
+                lds_read128_asm<1024>(tc[0][0], a0); lds_read128_asm<1024 + 64>(tc[0][1], a0);
+                lds_read128_asm<1024 + 128>(tc[1][0], a0); lds_read128_asm<1024 + 192>(tc[1][1], a0);
+                lds_read64_asm<0>(tr[0], r0); lds_read64_asm<128>(tr[1], r0); lds_read64_asm<256>(tr[2], r0);
+                lds_read64_asm<384>(tr[3], r0); lds_read64_asm<512>(tr[4], r0); lds_read64_asm<640>(tr[5], r0);
+                lds_read64_asm<768>(tr[6], r0); lds_read64_asm<896>(tr[7], r0);
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(tb[0][0]), "+v"(tb[0][1]), "+v"(tb[1][0]), "+v"(tb[1][1]), "+v"(tc[0][0]), "+v"(tc[0][1]),
+                               "+v"(tc[1][0]), "+v"(tc[1][1]), "+v"(tr[0]), "+v"(tr[1]), "+v"(tr[2]), "+v"(tr[3]), "+v"(tr[4]),
+                               "+v"(tr[5]), "+v"(tr[6]), "+v"(tr[7])
+                             :
+                             : "memory");
+            }
             f32x4_t bias4[2][2], cs4[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
-                    bias4[j][nf] = *reinterpret_cast<const f32x4_t*>(
-                        p.bias + tn0 + wc * 64 + j * 32 + nf * 16 + 4 * eq);
-                    cs4[j][nf] = ln ? *reinterpret_cast<const f32x4_t*>(p.colsum + tn0 + wc * 64 + j * 32 + nf * 16 + 4 * eq)
-                                    : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    bias4[j][nf] = __builtin_bit_cast(f32x4_t, tb[j][nf]);
+                    cs4[j][nf] = ln ? __builtin_bit_cast(f32x4_t, tc[j][nf]) : f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
             float2 rs8[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int mrow = tm0 + wr * 128 + k * 16 + e15;
-                rs8[k] = ln ? p.rowstat[mrow < p.M ? mrow : p.M - 1] : make_float2(1.0f, 0.0f);
-            }
-            char* ow = smem + G256P_STAGE + wave * 4096;
+            for (int k = 0; k < 8; ++k)
+                rs8[k] = ln ? make_float2(__uint_as_float((uint32_t)tr[k]), __uint_as_float((uint32_t)(tr[k] >> 32)))
+                            : make_float2(1.0f, 0.0f);
             const int rr = el >> 3, rc = el & 7;       // read-out: 8 rows per instruction, 16-B chunk rc
             bf16_t* const obase = (EPI == EPI_QKV)
                                       ? p.qk + (size_t)(tm0 + wr * 128 + rr) * (2 * p.D) + tn0 + wc * 64 + rc * 8
@@ -951,14 +1007,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
             int tv = tid;
             asm volatile("" : "+v"(tv));               // addresses rebuilt per tile (see above)
             const int l15 = tv & 15, q = (tv & 63) >> 4, tid = tv;
+            // the tile's epilogue terms in this wave's staging area (DMA of the tile's top; landed before the
+            // main loop's last wait): floats [0, 256) row terms, [256, 320) bias, [512, 576) column sums
+            const float* sterm = reinterpret_cast<const float*>(smem + G256P_STAGE + wave * 4096);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const int drow = wc * 64 + j * 32 + nf * 16 + l15;
-                    const bool ln = p.rowstat != nullptr;
-                    const float bias = p.bias[tn0 + drow], cs = ln ? p.colsum[tn0 + drow] : 0.0f;
+                    const float bias = sterm[256 + j * 32 + nf * 16 + l15];
+                    const float cs = ln ? sterm[512 + j * 32 + nf * 16 + l15] : 0.0f;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -966,16 +1025,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
                             const int qp = (p.vt_perm && !(p.tokens & 15)) ? ((q & 1) << 1 | (q >> 1)) : q;
                             const int c8 = wr * 32 + i * 16 + mf * 4 + qp;
                             const f32x4_t a = acc[i][mf][j][nf];
-                            float y[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {     // tokens 4q .. 4q+3 of this 16-row block
-                                const int mrow = tm0 + wr * 128 + i * 64 + mf * 16 + 4 * q + e;
-                                float2 rs = make_float2(1.0f, 0.0f);
-                                if (ln) rs = p.rowstat[mrow < p.M ? mrow : p.M - 1];
-                                y[e] = __builtin_fmaf(rs.x, a[e], __builtin_fmaf(rs.y, cs, bias));
+                            // row terms of tokens 4q .. 4q+3 of this 16-row block: 32 B of the wave's table
+                            f32x4_t r01 = {1.f, 0.f, 1.f, 0.f}, r23 = r01;
+                            if (ln) {
+                                r01 = *reinterpret_cast<const f32x4_t*>(sterm + (i * 64 + mf * 16 + 4 * q) * 2);
+                                r23 = *reinterpret_cast<const f32x4_t*>(sterm + (i * 64 + mf * 16 + 4 * q) * 2 + 4);
                             }
+                            const float y0 = __builtin_fmaf(r01[0], a[0], __builtin_fmaf(r01[1], cs, bias));
+                            const float y1 = __builtin_fmaf(r01[2], a[1], __builtin_fmaf(r01[3], cs, bias));
+                            const float y2 = __builtin_fmaf(r23[0], a[2], __builtin_fmaf(r23[1], cs, bias));
+                            const float y3 = __builtin_fmaf(r23[2], a[3], __builtin_fmaf(r23[3], cs, bias));
                             *reinterpret_cast<uint2*>(smem + drow * 512 + ((c8 ^ ((drow & 7) << 1)) << 3)) =
-                                make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                                make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
                         }
                 }
             __syncthreads();
@@ -1090,34 +1151,36 @@ hipError_t gemm256_prepare() {
     return prepare_one<EPI_F32>();
 }
 
-// hipErrorInvalidValue: the shape does not fit this kernel (the caller falls back to k_gemm.hip)
-hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st) {
-    if (a.M <= 0 || a.N % 256 != 0 || a.K % 64 != 0 || a.K < 128) return hipErrorInvalidValue;
-    // 32-bit byte offsets from the operand base pointers
-    if ((long long)a.M * a.lda * 2 >= (1ll << 31) || (long long)a.N * a.ldw * 2 >= (1ll << 31))
-        return hipErrorInvalidValue;
-    if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;
+// does the shape fit the 256x256 kernels? (launch_gemm takes the 4-wave kernel of k_gemm.hip otherwise)
+bool gemm256_fits(const GemmArgs& a, int epilogue) {
+    if (a.M <= 0 || a.N % 256 != 0 || a.K % 64 != 0 || a.K < 128) return false;
+    // unsigned 32-bit byte offsets from the operand base pointers (+ the K offset added to the base):
+    // vt_plan_engines keeps every engine below this (VT_GEMM256_MAX_OPERAND_BYTES)
+    if ((long long)a.M * a.lda * 2 >= VT_GEMM256_MAX_OPERAND_BYTES || (long long)a.N * a.ldw * 2 >= VT_GEMM256_MAX_OPERAND_BYTES)
+        return false;
+    if ((a.lda & 7) || (a.ldw & 7) || a.conv_grid > 0) return false;
     switch (epilogue) {
         case EPI_F32_POS:
         case EPI_RESID:
         case EPI_F32:
-            if ((a.ldx & 7) || !a.Xh || !a.Xl || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1)))
-                return hipErrorInvalidValue;
-            break;
+            return !((a.ldx & 7) || !a.Xh || !a.Xl || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1)));
         case EPI_GELU_BF16:
         case EPI_RELU_BF16:
-            if ((a.ldcb & 7) || !a.Cb || !a.bias || (a.rowstat && !a.colsum)) return hipErrorInvalidValue;
-            break;
+            return !((a.ldcb & 7) || !a.Cb || !a.bias || (a.rowstat && !a.colsum));
         case EPI_QKV:
-            if (a.D % 256 != 0 || a.N != 3 * a.D || (a.tokens & 3) ||
-                (a.npad & 3) || !a.bias || (a.rowstat && !a.colsum))
-                return hipErrorInvalidValue;
-            break;
-        default: return hipErrorInvalidValue;
+            return !(a.D % 256 != 0 || a.N != 3 * a.D || (a.tokens & 3) || (a.npad & 3) || !a.bias ||
+                     (a.rowstat && !a.colsum));
+        default: return false;
     }
+}
+
+// hipErrorInvalidValue: the shape does not fit this kernel
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st) {
+    if (!gemm256_fits(a, epilogue)) return hipErrorInvalidValue;
     if (ver == 3) {   // persistent: bf16 outputs, more tiles than CUs
         const int tiles = ((a.M + 255) / 256) * (a.N / 256);
         if (tiles <= 256) ver = 2;
+        else if (a.rowstat && (a.M & 1)) ver = 2;     // the row terms are fetched two rows per lane (16-B LDS-DMA)
         else switch (epilogue) {
             case EPI_GELU_BF16: return launch_persistent<EPI_GELU_BF16>(a, st);
             case EPI_RELU_BF16: return launch_persistent<EPI_RELU_BF16>(a, st);

@@ -99,15 +99,21 @@ struct GemmArgs {
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st);
-int gemm_pick_config(int M, int N, int K, int epilogue);
+int gemm_pick_config(int M, int N, int K, int epilogue, bool conv = false);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
 // k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
 #define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
 #define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
 #define GEMM_CFG_256PP 19      // v2, persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)
+// operands of the 256x256 kernels are addressed with unsigned 32-bit byte offsets from their base
+#define VT_GEMM256_MAX_OPERAND_BYTES (1ll << 32)
 hipError_t gemm256_prepare();
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st);
+bool gemm256_fits(const GemmArgs& a, int epilogue);
+// the tile configuration launch_gemm() runs for these arguments (the picker's choice, or the 4-wave
+// kernel where a 256x256 choice does not fit the operands)
+int gemm_effective_config(const GemmArgs& a, int epilogue);
 
 // y[r] (bf16) = LN(x[in_row(r)]) ; in_row(r) = (r / group) * in_stride + in_off + r % group
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,

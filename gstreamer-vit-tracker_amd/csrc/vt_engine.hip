@@ -113,11 +113,12 @@ struct Profiler {
 };
 
 
-// kernel-family label of a GEMM launch (built only when a profiler is attached)
-static const char* gemm_name(int epi, int M, int N, int K) {
+// kernel-family label of a GEMM launch (built only when a profiler is attached): the tile configuration
+// in it is the one launch_gemm() really runs for these arguments
+static const char* gemm_name(int epi, const GemmArgs& a) {
     static const char* tags[] = {"xpos", "xresid", "gelu", "relu", "qkv", "x"};
     static thread_local char buf[96];
-    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s_n%dk%d", tags[epi], gemm_config_name(gemm_pick_config(M, N, K, epi)), N, K);
+    snprintf(buf, sizeof(buf), "gemm_bf16_%s_%s_n%dk%d", tags[epi], gemm_config_name(gemm_effective_config(a, epi)), a.N, a.K);
     return buf;
 }
 
@@ -484,7 +485,7 @@ int Engine::run_pass(Profiler* prof) {
         // algorithmic bytes: operands once, output once; the residual pair is read and written (4 + 4 B)
         const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                           (epi == EPI_RESID ? 8.0 : epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
-        L(prof ? gemm_name(epi, a.M, a.N, a.K) : "", fl, by, [&] { return launch_gemm(a, epi, stream); });
+        L(prof ? gemm_name(epi, a) : "", fl, by, [&] { return launch_gemm(a, epi, stream); });
     };
     auto tap = [&](int slot) {
         if (taps && lerr == hipSuccess) {     // both halves of the residual stream: [slot][hi | lo][M][D]
@@ -883,7 +884,7 @@ int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void*
 
 void vt_release_dmabuf(vt_extmem* m) try {
     if (!m) return;
-    (void)hipSetDevice(m->device);
+    DeviceScope ds(m->device);             // the caller's current device is restored on return
     (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
     (void)hipDestroyExternalMemory(m->mem);
     delete m;
@@ -919,13 +920,25 @@ int vt_recommended_streams(const vt_model_info* info, int max_streams) try {
     return 1;
 } VT_NOTHROW_INT
 
+// largest engine for which every encoder GEMM still runs on the 256x256 kernels: they address an operand
+// with unsigned 32-bit byte offsets (k_gemm256.hip launch_gemm256), and the widest A operand of a pass is
+// max(dim, mlp_dim, kpad) bf16 columns by B * tokens rows
+static int engine_stream_cap(const vt_model_info* info) {
+    const long long tokens = (long long)info->tokens_template + info->tokens_search;
+    const long long width = std::max(std::max((long long)info->dim, (long long)info->mlp_dim), (long long)info->kpad);
+    if (tokens <= 0 || width <= 0) return VT_MAX_STREAMS;
+    const long long b = (VT_GEMM256_MAX_OPERAND_BYTES - 1) / (tokens * width * 2);
+    return (int)std::max(1LL, std::min((long long)VT_MAX_STREAMS, b));
+}
+
 int vt_plan_engines(const vt_model_info* info, int n_streams, int* sizes, int cap) try {
     if (!info || !sizes || n_streams < 1 || cap < 1) return 0;
     const int r = vt_recommended_streams(info, 128);
+    const int bmax = engine_stream_cap(info);
     int k;                                        // engines
     if (r <= 1 || n_streams <= r) k = 1;
     else k = 2;
-    while ((n_streams + k - 1) / k > VT_MAX_STREAMS) ++k;
+    while ((n_streams + k - 1) / k > bmax) ++k;
     if (k > cap) return 0;
     if (k == 2 && n_streams < 2 * r) {            // a full engine and the rest
         sizes[0] = r;
@@ -968,20 +981,33 @@ int vt_group_get_model_info(const vt_group* g, vt_model_info* out) try {
     fill_info(g->e, out);
     return VT_OK;
 } VT_NOTHROW_INT
+// A pipelined host pass (vt_group_enqueue_host) that has not been collected owns the stream states:
+// its redo path rewinds to the host's copy of them (`known`). Everything that would advance or
+// overwrite the states behind such a pass is refused until vt_group_wait_next has collected it.
+static int refuse_while_pipelined(const Engine* e, const char* what) {
+    if (e->host_seq != e->host_collected)
+        return set_err(VT_ERR_INVALID_ARG, "%s: collect the pipelined host passes first (vt_group_wait_next)", what);
+    return VT_OK;
+}
+
 int vt_group_init_device(vt_group* g, int stream, const vt_frame* frame, vt_bbox box) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    if (int rc = refuse_while_pipelined(g->e, "init")) return rc;
     return g->e->init_stream(stream, frame, box);
 } VT_NOTHROW_INT
 int vt_group_enqueue_device(vt_group* g, const vt_frame* frames, int n) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    if (int rc = refuse_while_pipelined(g->e, "enqueue_device")) return rc;
     return g->e->enqueue(frames, n);
 } VT_NOTHROW_INT
 int vt_group_wait(vt_group* g, vt_result* out, int n) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    if (int rc = refuse_while_pipelined(g->e, "wait")) return rc;      // its results live in the pass's slot
     return g->e->wait(out, n);
 } VT_NOTHROW_INT
 int vt_group_update_device(vt_group* g, const vt_frame* frames, int n, vt_result* out) try {
     if (!g) return set_err(VT_ERR_INVALID_ARG, "null group");
+    if (int rc = refuse_while_pipelined(g->e, "update_device")) return rc;
     if (int rc = g->e->enqueue(frames, n)) return rc;
     return g->e->wait(out, n);
 } VT_NOTHROW_INT
@@ -993,6 +1019,7 @@ int vt_group_init_host(vt_group* g, int stream, const vt_frame* host_frame, vt_b
     if (!g || !host_frame) return set_err(VT_ERR_INVALID_ARG, "null argument");
     Engine* e = g->e;
     if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
+    if (int rc = refuse_while_pipelined(e, "init_host")) return rc;
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));     // the staging arena is shared by the group's passes
     const float fb[1][4] = {{(float)box.x, (float)box.y, (float)box.width, (float)box.height}};
@@ -1036,6 +1063,7 @@ int vt_group_set_state_box(vt_group* g, int stream, const float* box4) try {
     Engine* e = g->e;
     if (stream < 0 || stream >= e->B) return set_err(VT_ERR_INVALID_ARG, "bad stream index");
     if (!e->h_initialized[stream]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", stream);
+    if (int rc = refuse_while_pipelined(e, "set_state_box")) return rc;
     for (int k = 0; k < 4; ++k)
         if (!std::isfinite(box4[k])) return set_err(VT_ERR_INVALID_ARG, "state box: non-finite value");
     if (!(box4[2] >= 1.0f) || !(box4[3] >= 1.0f) || box4[2] > 32768.0f || box4[3] > 32768.0f ||
@@ -1055,6 +1083,7 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
     if (!g || !frames || !out || iters < 1) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     Engine* e = g->e;
     if (n != e->B) return set_err(VT_ERR_INVALID_ARG, "profile: need exactly %d frames", e->B);
+    if (int rc = refuse_while_pipelined(e, "profile")) return rc;
     for (int b = 0; b < e->B; ++b)
         if (!e->h_initialized[b]) return set_err(VT_ERR_NOT_INITIALIZED, "stream %d not initialised", b);
     DEVICE_SCOPE(e->device);
@@ -2016,18 +2045,15 @@ struct RcclApi {
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
-RcclApi* rccl_api() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.ok ? &api : nullptr;
-    tried = true;
+RcclApi load_rccl() {
+    RcclApi api;
     void* h = RTLD_DEFAULT;                          // a copy already loaded by the host wins
     if (!dlsym(h, "ncclGetUniqueId")) {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         h = nullptr;
         for (const char* n : names)
             if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!h) return nullptr;
+        if (!h) return api;
     }
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
@@ -2035,6 +2061,12 @@ RcclApi* rccl_api() {
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
     api.ok = api.GetUniqueId && api.CommInitRank && api.Broadcast && api.CommDestroy;
+    return api;
+}
+// one host thread per GPU may call in at the same time: a C++11 magic static hands every caller the
+// fully built table (initialisation runs once, the others wait for it)
+RcclApi* rccl_api() {
+    static RcclApi api = load_rccl();
     return api.ok ? &api : nullptr;
 }
 int rccl_err(RcclApi* a, const char* what, int code) {

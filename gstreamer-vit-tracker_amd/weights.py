@@ -340,6 +340,37 @@ def ensure_weights(cfg_name: str, path: str | None = None, head: dict | None = N
     return path
 
 
+def engine_stream_cap(cfg: "ModelConfig | str", max_streams: int = 1024) -> int:
+    """largest engine for which every encoder GEMM still runs on the 256x256 kernels: they address an
+    operand with unsigned 32-bit byte offsets, and the widest A operand of a pass is max(dim, mlp_dim,
+    kpad) bf16 columns by B * tokens rows (mirror of engine_stream_cap in csrc/vt_engine.hip)"""
+    if isinstance(cfg, str):
+        cfg = get_config(cfg)
+    width = max(cfg.dim, cfg.mlp_dim, cfg.kpad)
+    return max(1, min(max_streams, ((1 << 32) - 1) // (cfg.n_tokens * width * 2)))
+
+
+def plan_engines(cfg: "ModelConfig | str", n_streams: int) -> list:
+    """Engine (Group) sizes for n_streams on one GPU (mirror of vt_plan_engines in the C ABI): one
+    engine up to R = recommended_streams(cfg); an engine of R plus one with the rest below 2R (the two
+    engines' kernels overlap on the chip, so the second one's nearly empty rounds cost little: ViT-B/16
+    t192/s384, 31 streams: 172 us per frame as 30 + 1, 197 in one engine, 164 at 30 streams); two
+    engines of n/2 from 2R on (31 + 30: 165 us; three concurrent engines measured worse than two:
+    profiles/r02_engine_splits.txt); never an engine beyond engine_stream_cap. bench.py and the tests
+    use the C ABI's vt_plan_engines; this mirror exists for hosts that plan before loading the library
+    and is swept against it in tests/test_weights_and_oracle_model.py."""
+    if n_streams < 1:
+        raise ValueError("n_streams < 1")
+    r = recommended_streams(cfg)
+    bmax = engine_stream_cap(cfg)
+    k = 1 if (r <= 1 or n_streams <= r) else 2
+    while -(-n_streams // k) > bmax:
+        k += 1
+    if k == 2 and n_streams < 2 * r:
+        return [r, n_streams - r]
+    return [n_streams // k + (1 if i < n_streams % k else 0) for i in range(k)]
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="write a synthetic weight blob")
@@ -347,21 +378,3 @@ if __name__ == "__main__":
     ap.add_argument("-o", "--out", default=None)
     a = ap.parse_args()
     print(ensure_weights(a.config, a.out, force=True))
-
-
-def plan_engines(cfg: "ModelConfig | str", n_streams: int, max_per_engine: int = 1024) -> list:
-    """Engine (Group) sizes for n_streams on one GPU (mirror of vt_plan_engines in the C ABI): one
-    engine up to R = recommended_streams(cfg); an engine of R plus one with the rest below 2R (the two
-    engines' kernels overlap on the chip, so the second one's nearly empty rounds cost little: ViT-B/16
-    t192/s384, 31 streams: 172 us per frame as 30 + 1, 197 in one engine, 164 at 30 streams); two
-    engines of n/2 from 2R on (31 + 30: 165 us; three concurrent engines measured worse than two:
-    profiles/r02_engine_splits.txt)."""
-    if n_streams < 1:
-        raise ValueError("n_streams < 1")
-    r = recommended_streams(cfg)
-    k = 1 if (r <= 1 or n_streams <= r) else 2
-    while -(-n_streams // k) > max_per_engine:
-        k += 1
-    if k == 2 and n_streams < 2 * r:
-        return [r, n_streams - r]
-    return [n_streams // k + (1 if i < n_streams % k else 0) for i in range(k)]

@@ -238,9 +238,13 @@ int vt_group_update_host(vt_group* g, const vt_frame* host_frames, int n, vt_res
  * While a pass is running its boxes are not known, so the window of the next frame is cut around the
  * last KNOWN box, enlarged to cover a target that moves by a quarter of the search crop and grows by a
  * quarter in one frame (1.75x the crop side). The pixel kernel flags a pass that needed a pixel outside
- * the window it was given; vt_group_wait_next then restores the stream states from a device-side
- * snapshot and redoes that pass (and the one queued behind it) with exact windows, so the results are
- * always those of the full frames. (host -> tracker: src/pipeline.rs:95-101 maps the buffer on the CPU) */
+ * the window it was given; vt_group_wait_next then restores the stream states from the HOST's copy of
+ * the states the previous pass left (collected by the wait_next before it) and redoes that pass (and
+ * the one queued behind it) with exact windows, so the results are always those of the full frames.
+ * While a pass is outstanding it owns the stream states: every entry point that would advance or
+ * overwrite them (vt_group_init_*, vt_group_enqueue_device, vt_group_update_device / _host,
+ * vt_group_wait, vt_group_set_state_box, vt_group_profile_device) returns VT_ERR_INVALID_ARG until
+ * vt_group_wait_next has collected it. (host -> tracker: src/pipeline.rs:95-101 maps the buffer on the CPU) */
 int vt_group_enqueue_host(vt_group* g, const vt_frame* host_frames, int n);
 int vt_group_wait_next(vt_group* g, vt_result* out, int n);
 /* passes vt_group_wait_next had to redo because a speculative window missed (since creation) */

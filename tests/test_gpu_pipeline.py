@@ -292,6 +292,36 @@ def test_batched_30_streams_cfg3_large_tile_path(gpu, oracle, weights_cfg3):
             assert d <= 1 and abs(res[i].score - r.score) < 0.03, (t, i, res[i], r)
 
 
+def test_large_engine_keeps_the_256x256_kernels_and_matches_the_30_stream_engine(gpu, weights_cfg3):
+    """vt_plan_engines hands out engines of up to 970 cfg3 streams; the 256x256 kernels address their
+    operands with unsigned 32-bit byte offsets (fc2's A operand of 330 streams is 1.46 GB, beyond the
+    signed range the round-2 kernels stopped at). One engine of 330 streams (M = 237,600): every stream
+    is fed the same two frames, so (a) all 330 results must be identical to each other and (b) equal to
+    what the 30-stream engine gives for that input up to the per-kernel tile order (+-1 px, 0.02)."""
+    B, w, h = 330, 1920, 1080
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=411)
+    big = gpu.Group(weights_cfg3, n_streams=B)
+    small = gpu.Group(weights_cfg3, n_streams=30)
+    f0, f1 = gpu.NV12Frame(sc.frame_nv12(0), w, h), gpu.NV12Frame(sc.frame_nv12(1), w, h)
+    box = gpu.BBox.new(*sc.gt_box(0))
+    for i in range(B):
+        big.init_host(i, f0, box)
+    for i in range(30):
+        small.init_host(i, f0, box)
+    for f in (f0, f1):
+        rb, rs = big.update_host([f] * B), small.update_host([f] * 30)
+        assert all(r.bbox == rb[0].bbox and r.score == rb[0].score and r.success for r in rb)
+        assert np.abs(np.array(rb[0].bbox) - np.array(rs[0].bbox)).max() <= 1 and abs(rb[0].score - rs[0].score) < 0.02
+    for i in (0, 157, 329):
+        assert big.read_state(i)["frames_done"] == 2 and big.read_state(i)["success_count"] == 2
+    # the per-kernel profile names the tile configuration launch_gemm() really ran: all encoder GEMMs 256x256
+    import torch
+    d = torch.from_numpy(sc.frame_nv12(2)).cuda()
+    fr = gpu.frame_nv12(d.data_ptr(), d.data_ptr() + w * h, w, h)
+    names = [k["name"] for k in big.profile_device([fr] * B, iters=1) if k["name"].startswith("gemm") and "relu" not in k["name"]]
+    assert len(names) == 5 and all("256x256" in nm for nm in names), names
+
+
 def test_planned_engines_run_concurrently_and_track_like_one_engine(gpu, weights_cfg3):
     """vt_plan_engines splits 33 ViT-B/16 streams into engines of 30 + 3 (no engine just past a GEMM
     round boundary). Both engines are enqueued before either is waited for, so their kernels share
@@ -650,6 +680,18 @@ def test_pipelined_host_passes_equal_synchronous_ones(gpu, weights_tiny, margin_
     pipe.enqueue_host(frames[0]); pipe.enqueue_host(frames[1])
     with pytest.raises(gpu.VtError):
         pipe.enqueue_host(frames[2])          # two passes outstanding
+    # an outstanding pass owns the stream states (its redo path rewinds to the host's copy of them):
+    # everything that would advance or overwrite them behind it is refused, and changes nothing
+    before = [pipe.read_state(i) for i in range(B)]
+    for call in (lambda: pipe.update_host(frames[2]), lambda: pipe.wait(),
+                 lambda: pipe.init_host(0, frames[0][0], gpu.BBox.new(*scs[0].gt_box(0))),
+                 lambda: pipe.set_state_box(0, [10.0, 10.0, 50.0, 50.0])):
+        with pytest.raises(gpu.VtError) as ei:
+            call()
+        assert ei.value.code == -1 and "vt_group_wait_next" in str(ei.value)      # VT_ERR_INVALID_ARG
     pipe.wait_next(); pipe.wait_next()
+    after = [pipe.read_state(i) for i in range(B)]
+    for i in range(B):
+        assert after[i]["frames_done"] == before[i]["frames_done"] or after[i]["frames_done"] == n + 2
     # the synchronous entry point still works afterwards and continues the same state chain
     assert len(pipe.update_host(frames[2])) == B

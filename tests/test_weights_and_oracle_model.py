@@ -140,18 +140,23 @@ def test_engine_plan_keeps_every_engine_off_the_tile_count_cliff(vt):
     assert vt.weights.plan_engines("cfg3", 61) == [31, 30]
     assert vt.weights.plan_engines("cfg3", 90) == [45, 45]
     assert vt.weights.plan_engines("tiny", 50) == [50]            # no 256-wide kernel: nothing to plan
-    assert vt.weights.plan_engines("cfg3", 3000) == [1000, 1000, 1000]
+    # no engine beyond the largest batch whose GEMM operands the 256x256 kernels can address (unsigned
+    # 32-bit byte offsets: B * tokens * mlp_dim * 2 < 2^32 -> 970 streams on cfg3, 534 on cfg5)
+    assert vt.weights.engine_stream_cap("cfg3") == 970 and vt.weights.engine_stream_cap("cfg5") == 534
+    assert vt.weights.plan_engines("cfg3", 3000) == [750, 750, 750, 750]
+    assert vt.weights.plan_engines("cfg5", 1000) == [500, 500]
     with pytest.raises(ValueError):
         vt.weights.plan_engines("cfg3", 0)
+    # the Python mirror against the C ABI's planner (what bench.py and a host use), swept
     for name in ("cfg2", "cfg3", "cfg5", "tiny"):
         cfg = vt.weights.get_config(name)
         mi = vt.CModelInfo()
-        mi.dim, mi.mlp_dim = cfg.dim, cfg.mlp_dim
+        mi.dim, mi.mlp_dim, mi.kpad = cfg.dim, cfg.mlp_dim, cfg.kpad
         mi.tokens_template, mi.tokens_search = cfg.n_t, cfg.n_s
-        for n in (1, 2, 29, 30, 31, 33, 34, 59, 60, 61, 67, 68, 133, 134, 135, 200, 1024, 1025, 2049):
+        for n in list(range(1, 301)) + [533, 534, 535, 969, 970, 971, 1024, 1025, 1941, 2049, 3000, 5000]:
             got = vt.plan_engines(mi, n)
             assert got == vt.weights.plan_engines(name, n), (name, n)
-            assert sum(got) == n and all(0 < g <= 1024 for g in got)
+            assert sum(got) == n and all(0 < g <= vt.weights.engine_stream_cap(name) for g in got)
     with pytest.raises(ValueError):
         vt.plan_engines(mi, 0)
 
