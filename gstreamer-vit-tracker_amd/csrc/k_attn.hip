@@ -414,21 +414,20 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // NS: ring stages of 16 KiB (3: two tiles ahead, 48 KiB -> 3 workgroups per CU; 2: one tile ahead,
 // 32 KiB -> 4 workgroups per CU if the kernel also fits 128 registers); WPS: waves per SIMD the
 // register allocation must allow.
-template <int ORD, int NS, int WPS>
-__global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
-                                                            const bf16_t* __restrict__ vt,
-                                                            bf16_t* __restrict__ out, int tokens,
-                                                            int H, int npad, int stagger) {
-    __shared__ __attribute__((aligned(16))) char smem[NS * AT3_STAGE];
-    // Three workgroups share a CU (one wave of each per SIMD). Dispatched together and running the
-    // same code they sit in the same phase of the step at the same time, so their MFMA, softmax-VALU
-    // and memory parts add up on the SIMD instead of overlapping (profiles/README.md). `stagger`
-    // delays the workgroups of the first residency wave by 0, 1/3 and 2/3 of a step.
-    if (stagger) {
-        const int k = (int)(blockIdx.x / 256u) % 3;
-        for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
+// One pass of a workgroup over its (stream, head, 128 queries). CAREFUL = false (ORD 0 only): the FIRST
+// pass takes p = 2^score as it is, with no running maximum at all - per step 16 v_max3, a cross-half
+// swap, a ballot and a branch less, and the exponentials start the moment the scores leave the matrix
+// pipe. Afterwards every query's row sum must lie in [2^-60, 2^60] (it does whenever the scores stayed
+// within about +-60 log2 units; an overflow gives inf or NaN, which fail the test too); if any query of
+// the workgroup fails, nothing is stored and the function returns true: the kernel then runs the
+// CAREFUL pass (the windowed reference described below) on the same block. While no score leaves the
+// +-32 window the two passes are the same arithmetic. Two inlined copies, one after the other, rather
+// than a loop with a flag: with a back edge hipcc keeps the whole set-up live (190 VGPRs, 98 spilled
+// SGPRs: two waves per SIMD instead of three).
+template <int ORD, int NS, bool CAREFUL>
+__device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                         bf16_t* __restrict__ out, int tokens, int H, int npad, int tid, int block) {
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int D = H * 64, ld = 2 * D;
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
     // read the same K and Vt (184 KB at 720 tokens): give each XCD a contiguous run of the 1-D grid
     // so that they share one L2 instead of pulling the head's K/Vt into six of them (measured
     // before this remap: the kernel ran at the HBM rate of 6x the K/V bytes).
-    int bid = blockIdx.x;
+    int bid = block;
     {
         const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -446,6 +445,8 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
     const int h = bh % H, b = bh / H;
     const int qb = xb * 4 + wave;
 
+    f32x16_t o0, o1, osum;
+    constexpr bool careful = CAREFUL;
     const int q = qb * 32 + l31;
     const int qc = q < tokens ? q : tokens - 1;     // idle rows repeat the last query, never stored
     const bf16_t* qrow = qk + ((size_t)b * tokens + qc) * ld + h * 64 + half * 8;
@@ -487,9 +488,6 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
 
     // O^T accumulators; osum = ones · P^T: every register of it ends up holding the row sum of the
     // lane's query (summed over both lane halves by the MFMA itself); only register 0 is used.
-    f32x16_t o0, o1, osum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; osum[r] = 0.0f; }
     // Softmax reference: p = 2^(score - m_run). m_run stays 0 - no subtraction pass at all - while
     // every query's scores stay inside [-ATT_WIN, +ATT_WIN] log2 units (p <= 2^32 is harmless in
     // bf16 / f32 and the normalisation at the end divides it out); it moves, with a rescale of what
@@ -498,8 +496,9 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
     float m_run = 0.0f;
     bool shifted = false;                // wave-uniform: some lane's m_run != 0
     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-
     constexpr int AHEAD = NS - 1;        // tiles in flight beyond the one being computed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; osum[r] = 0.0f; }
     AT3_STAGE_TILE(0, 0)
     if (AHEAD > 1 && nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
     int sbase = 0;                       // LDS offset of the stage holding tile kt
@@ -677,6 +676,7 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
                     if (key + 32 >= tokens) s1[r] = -INFINITY;
                 }
             }
+            if constexpr (careful) {
             if (shifted) {                      // wave-uniform, rare: scores relative to the moved reference
     #pragma unroll
                 for (int r = 0; r < 16; ++r) { s0[r] -= m_run; s1[r] -= m_run; }
@@ -703,6 +703,7 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
                     s0[r] -= dm; s1[r] -= dm;
                 }
             }
+            }   // careful
             bf16x8_t pf[4];
     #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -725,10 +726,23 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
         }   // ORD != 2
         sbase = sbase + AT3_STAGE >= NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
     }
+    __syncthreads();                      // every wave is done reading the ring
+    if constexpr (!careful) {
+        // did every query of the workgroup stay in range? (the barriers of a pass are workgroup-wide, so
+        // the four waves repeat together or not at all; the flags live in the dead ring)
+        const float l = osum[0];
+        const bool bad = !(l >= 0x1p-60f && l <= 0x1p60f);
+        const unsigned long long bm = __ballot(bad);
+        int* flag = reinterpret_cast<int*>(smem);
+        if (lane == 0) flag[wave] = bm != 0ull;
+        __syncthreads();
+        const int any = flag[0] | flag[1] | flag[2] | flag[3];
+        __syncthreads();                  // flags read before anything overwrites them
+        if (any) return true;
+    }
     const float l_run = osum[0];
 
     // ---- epilogue: O^T (d on registers, query on lanes) -> LDS [32 q][128 B] per wave -> rows ----
-    __syncthreads();                      // every wave is done reading the ring
     {
         const float inv = 1.0f / l_run;
         char* ow = smem + wave * 4096;     // 32 rows x 128 B, chunk c of row r at c ^ (r & 7)
@@ -753,6 +767,38 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
                 *reinterpret_cast<uint4*>(out + ((size_t)b * tokens + qq) * D + h * 64 + c * 8) = v;
         }
     }
+    return false;
+}
+
+template <int ORD, int NS, int WPS>
+__global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
+                                                            const bf16_t* __restrict__ vt,
+                                                            bf16_t* __restrict__ out, int tokens,
+                                                            int H, int npad, int stagger) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * AT3_STAGE];
+    // Three workgroups share a CU (one wave of each per SIMD). Dispatched together and running the
+    // same code they sit in the same phase of the step at the same time, so their MFMA, softmax-VALU
+    // and memory parts add up on the SIMD instead of overlapping (profiles/README.md). `stagger`
+    // delays the workgroups of the first residency wave by 0, 1/3 and 2/3 of a step.
+    if (stagger) {
+        const int k = (int)(blockIdx.x / 256u) % 3;
+        for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+    if constexpr (ORD == 0) {
+        if (at3_pass<0, NS, false>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
+            __syncthreads();
+            // the (rare) second pass rebuilds every address from opaque copies of its inputs: if the
+            // compiler could see that the two inlined passes compute the same values it would keep the
+            // first pass's alive for the second (189 VGPRs instead of 156: a wave per SIMD less)
+            int t2 = threadIdx.x, b2 = blockIdx.x, tk = tokens, hh = H, np2 = npad;
+            const bf16_t* q2 = qk; const bf16_t* v2 = vt; bf16_t* o2 = out;
+            asm volatile("" : "+v"(t2));
+            asm volatile("" : "+s"(b2), "+s"(tk), "+s"(hh), "+s"(np2), "+s"(q2), "+s"(v2), "+s"(o2));
+            at3_pass<0, NS, true>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
+        }
+    } else {
+        at3_pass<ORD, NS, true>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
+    }
 }
 
 // mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
@@ -761,7 +807,8 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
 // softmax per 32 keys with QK(b) under softmax(a) (74 vs 70 us at 30 streams), 5 = 2-stage ring and
 // sequential halves in 119 registers = four workgroups per CU (76.8 vs 72.8 us: a fourth wave per
 // SIMD does not help - MFMA and VALU time of this instruction mix add up on a SIMD whatever the
-// number of waves; a 2-stage ring alone is as fast as the 3-stage one, 72.3 us).
+// number of waves; a 2-stage ring alone is as fast as the 3-stage one, 72.3 us); 6 = mode 3's careful
+// pass alone (the default until round 3).
 int attention_pick_mode(int tokens, int npad) {
     if (npad % 64 != 0) return 0;
     return (tokens % 4 == 0) ? 3 : 2;   // tokens % 4: the QKV epilogue's 4-token runs stay inside a stream
@@ -786,7 +833,12 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
         hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
     } else if (mode == 3) {
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc
+        // then spills (100 B of scratch) sits in the rare second pass only (checked in the ISA)
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 6) {               // tuning only: mode 3 without the unchecked first pass (round 2's kernel)
+        hipLaunchKernelGGL((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
         hipLaunchKernelGGL((attention_dma_kernel<1, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,

@@ -682,6 +682,11 @@ int gemm_effective_config(const GemmArgs& a, int epilogue) {
     return cfg;
 }
 
+bool gemm_finalizes_rowstat(const GemmArgs& a, int epilogue) {
+    const bool x_epi = epilogue == EPI_F32_POS || epilogue == EPI_RESID || epilogue == EPI_F32;
+    return x_epi && a.rowstat_out && a.panel_cnt && a.cstat && a.N <= 1536 && gemm_effective_config(a, epilogue) >= GEMM_CFG_256P8;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {
     const int cfg = gemm_effective_config(a, epilogue);
     hipError_t e = launch_gemm_cfg(a, epilogue, cfg, st);

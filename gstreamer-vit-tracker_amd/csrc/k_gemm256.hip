@@ -405,6 +405,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int nf = 0; nf < 2; ++nf) acc[i][mf][j][nf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
+        // the bias is the accumulators' initial value (lane = row, registers = 4 consecutive columns): one
+        // add per element less in an epilogue whose vector work is not hidden by anything
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wc * 64 + j * 32 + nf * 16 + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf) acc[i][mf][j][nf] = b4;
+                }
+        }
         if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
         else g256_mainloop<true>(p, smem, m0, n0, acc);
         // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics (vt_common.hpp) ----------
@@ -417,9 +431,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // fragments are dead) are issued BEFORE the accumulators are staged, and those of pass 1 before
         // pass 0 is written out, so their latency runs under LDS staging and the stores.
         const int c8 = lane & 31, rsub = lane >> 5, n8 = n0 + c8 * 8;
-        float bias8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = p.bias ? p.bias[n8 + e] : 0.0f;
         const int nchunk = p.N / VT_STAT_CHUNK;
         // row pair `it` (0..7) of pass i that this wave writes out: pass rows lr = it*16 + wave*2 + rsub
         auto out_row = [&](int i, int it) { const int lr = it * 16 + wave * 2 + rsub; return m0 + (lr >> 6) * 128 + i * 64 + (lr & 63); };
@@ -466,8 +477,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x[e] = (f0[e] + bias8[e]) + add[e];
-                    x[4 + e] = (f1[e] + bias8[4 + e]) + add[4 + e];
+                    x[e] = f0[e] + add[e];
+                    x[4 + e] = f1[e] + add[4 + e];
                 }
                 float csum, cm2;
                 x_chunk_stats(x, csum, cm2);
@@ -476,8 +487,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 if (m < p.M) {
                     *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
                     *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
-                    if (p.cstat && (c8 & 3) == 0)
-                        p.cstat[(size_t)m * nchunk + (n8 / VT_STAT_CHUNK)] = make_float2(csum, cm2);
+                    if (p.cstat && (c8 & 3) == 0) {
+                        // write-through (sc1) store: the row panel's last workgroup may read it in this
+                        // launch (finalize below); the same bytes either way
+                        const unsigned long long bits = ((unsigned long long)__float_as_uint(cm2) << 32) | __float_as_uint(csum);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.cstat + (size_t)m * nchunk + (n8 / VT_STAT_CHUNK)),
+                                           bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         };
@@ -494,6 +510,68 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         stage_pass(1);
         __syncthreads();
         write_pass(1, ad1);
+        // ---- row terms of the LayerNorm that follows, by the LAST workgroup of the row panel ------------
+        // (instead of a launch of their own: 24 per pass, 6.5 us each between 40-90 us GEMMs.) The N / 256
+        // workgroups of a 256-row panel each stored their chunk partials write-through; every wave drains
+        // its stores, the workgroup's barrier, then ONE lane takes a ticket on the panel's counter
+        // (agent-scope add). The workgroup whose add came last - told by the value the add returned - reads
+        // the panel's partials with sc1 loads behind a workgroup barrier that lane has joined, combines them
+        // per row (parallel-variance form, as launch_rowstat_finalize does) and stores (rstd, -mean * rstd)
+        // for the next kernel. That is the first row of the table of hand-offs measured with sc1 loads in
+        // place of an acquire (MI355X guide, "Valid forms": one signalling lane per workgroup after every
+        // storing wave's vmcnt(0); one 128-KiB-LDS workgroup per CU; 8-B sc1 stores and loads); no dispatch
+        // order, timing or placement is assumed. The counter is left at zero for the next launch.
+        if (p.rowstat_out) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* s_last = reinterpret_cast<int*>(smem);
+            const int tiles_n_ = p.N >> 8, panel = m0 >> 8;
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(p.panel_cnt + panel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = t == (unsigned)(tiles_n_ - 1);
+                if (last) __hip_atomic_store(p.panel_cnt + panel, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_last = last;
+            }
+            __syncthreads();
+            if (*s_last) {
+                // two lanes per row, each half of the row's chunks: nchunk / 4 sc1 loads of 16 B (two
+                // chunks each), all issued before the one wait (agent-scope atomic loads are waited for
+                // one by one by hipcc: 24 dependent round trips at the end of every launch)
+                const int row = tid >> 1, hpart = tid & 1, m = m0 + row;
+                const int mc = m < p.M ? m : p.M - 1;
+                const char* src = reinterpret_cast<const char*>(p.cstat + (size_t)mc * nchunk) + hpart * (nchunk * 4);
+                const int nl = nchunk >> 2;                  // N % 256 == 0: nchunk is a multiple of 8
+                u32x4_t v[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    v[i] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (i < nl) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(src + i * 16) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])
+                             :
+                             : "memory");
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    if (i < nl) s += __uint_as_float(v[i][0]) + __uint_as_float(v[i][2]);
+                s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+                const float Dn = (float)p.N, mean = s / Dn;
+                float m2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    if (i < nl) {
+                        const float d0 = __uint_as_float(v[i][0]) * (1.0f / VT_STAT_CHUNK) - mean;
+                        const float d1 = __uint_as_float(v[i][2]) * (1.0f / VT_STAT_CHUNK) - mean;
+                        m2 += (__uint_as_float(v[i][1]) + (float)VT_STAT_CHUNK * (d0 * d0)) +
+                              (__uint_as_float(v[i][3]) + (float)VT_STAT_CHUNK * (d1 * d1));
+                    }
+                m2 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, m2), 0xB1, 0xF, 0xF, true));
+                const float rstd = 1.0f / sqrtf(m2 / Dn + p.ln_eps);
+                if (hpart == 0 && m < p.M) p.rowstat_out[m] = make_float2(rstd, -mean * rstd);
+            }
+        }
     } else {
         bool v_tile = false;
         float scale = 1.0f;

@@ -81,6 +81,11 @@ struct GemmArgs {
     int M, N, K;
     bf16_t* Xh; bf16_t* Xl; int ldx;   // X-epilogues: the residual stream pair [M][ldx] (EPI_RESID: read, then written)
     float2* cstat;                // X-epilogues: [M][N / 32] chunk partials (sum, M2), or null
+    // X-epilogues of the 256x256 kernel (launch_gemm reports whether it was used): the last workgroup of
+    // every 256-row panel finalizes the panel's row terms itself (no launch_rowstat_finalize needed)
+    float2* rowstat_out;          // [M] (rstd, -mean * rstd), or null
+    unsigned* panel_cnt;          // [ceil(M / 256)] arrival counters, zero between launches
+    float ln_eps;
     bf16_t* Cb; int ldcb;         // bf16 output
     const float* pos; int pos_rows;     // EPI_F32_POS: [pos_rows][ldx] f32
     const float2* rowstat;        // bf16 epilogues: folded LayerNorm row terms [M] (rstd, -mean * rstd), or null
@@ -98,6 +103,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);
+// true: launch_gemm() will run an X-epilogue of these arguments on the 256x256 kernel, whose row panels
+// finalize a.rowstat_out themselves; false: the caller launches launch_rowstat_finalize behind the GEMM
+bool gemm_finalizes_rowstat(const GemmArgs& a, int epilogue);
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st);
 int gemm_pick_config(int M, int N, int K, int epilogue, bool conv = false);
 const char* gemm_config_name(int cfg);

@@ -140,6 +140,7 @@ struct Engine {
     // folded LayerNorm (vt_common.hpp); folded weights of all layers
     bf16_t *d_xh = nullptr, *d_xl = nullptr, *d_foldw = nullptr, *d_taps = nullptr;
     float2 *d_cstat = nullptr, *d_rstat = nullptr;
+    unsigned* d_panel_cnt = nullptr;   // arrival counters of the 256-row panels (X-epilogues of the 256x256 kernel)
     float *d_foldv = nullptr, *d_headout = nullptr;
     StreamState* d_states = nullptr;
     FrameDesc* d_frames = nullptr;
@@ -213,7 +214,7 @@ void Engine::destroy() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     void* devp[] = {d_blob, d_patches, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
-                    d_xh, d_xl, d_cstat, d_rstat, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
+                    d_xh, d_xl, d_cstat, d_rstat, d_panel_cnt, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
                     d_results, d_stage};
     for (void* p : devp)
         if (p) (void)hipFree(p);
@@ -402,6 +403,7 @@ int Engine::alloc_buffers() {
     HIPCHK(dalloc0(&d_xl, M * d.D));
     HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK)));
     HIPCHK(dalloc0(&d_rstat, M));
+    HIPCHK(dalloc0(&d_panel_cnt, (M + 255) / 256 + 1));
     {   // fold LayerNorm 1 / 2 of every layer into the QKV / fc1 weights
         const size_t rows = (size_t)3 * d.D + d.mlp;
         HIPCHK(dalloc0(&d_foldw, (size_t)d.L * rows * d.D));
@@ -496,10 +498,21 @@ int Engine::run_pass(Profiler* prof) {
         }
     };
     const int nchunk = D / VT_STAT_CHUNK;
-    // row terms (rstd, -mean * rstd) of the LayerNorm that follows an X-epilogue, from its chunk partials
-    auto rowstats = [&] {
-        L("rowstat", 0, (double)M * (nchunk + 1) * 8,
-          [&] { return launch_rowstat_finalize(d_cstat, d_rstat, M, nchunk, d.ln_eps, stream); });
+    // An X-epilogue GEMM (writes the residual pair) followed by the row terms (rstd, -mean * rstd) of the
+    // LayerNorm that consumes it: finalized inside the GEMM by the last workgroup of every row panel (the
+    // 256x256 kernel), else by a small launch of their own from the chunk partials
+    auto xgemm = [&](int epi, GemmArgs a, bool stats) {
+        a.Xh = d_xh; a.Xl = d_xl; a.ldx = D;
+        a.cstat = stats ? d_cstat : nullptr;
+        a.rowstat_out = stats ? d_rstat : nullptr;
+        a.panel_cnt = d_panel_cnt;
+        a.ln_eps = d.ln_eps;
+        const bool fused = stats && gemm_finalizes_rowstat(a, epi);
+        if (!fused) a.rowstat_out = nullptr;
+        gemm(epi, a);
+        if (stats && !fused)
+            L("rowstat", 0, (double)M * (nchunk + 1) * 8,
+              [&] { return launch_rowstat_finalize(d_cstat, d_rstat, M, nchunk, d.ln_eps, stream); });
     };
 
     // K1: crop + resize + normalise the search window of every stream -> patch rows
@@ -512,15 +525,13 @@ int Engine::run_pass(Profiler* prof) {
         a.W = (const bf16_t*)find("patch_w")->ptr; a.ldw = d.kpad;
         a.bias = (const float*)find("patch_b")->ptr;
         a.M = M; a.N = D; a.K = d.kpad;
-        a.Xh = d_xh; a.Xl = d_xl; a.ldx = D; a.cstat = d_cstat;
         a.pos = (const float*)find("pos")->ptr; a.pos_rows = d.ntok;
-        gemm(EPI_F32_POS, a);
+        xgemm(EPI_F32_POS, a, true);        // + the row terms of block 0's LayerNorm 1
     }
     tap(0);
     for (int l = 0; l < d.L; ++l) {
         const LayerW& w = layers[l];
-        rowstats();                         // LayerNorm 1, folded into the QKV GEMM
-        {
+        {   // LayerNorm 1 is folded into the QKV GEMM
             GemmArgs a{};
             a.A = d_xh; a.lda = D; a.W = w.qkv_wf; a.ldw = D; a.bias = w.qkv_c;
             a.rowstat = d_rstat; a.colsum = w.qkv_cs;
@@ -535,11 +546,10 @@ int Engine::run_pass(Profiler* prof) {
         {
             GemmArgs a{};
             a.A = d_attn; a.lda = D; a.W = w.proj_w; a.ldw = D; a.bias = w.proj_b;
-            a.M = M; a.N = D; a.K = D; a.Xh = d_xh; a.Xl = d_xl; a.ldx = D; a.cstat = d_cstat;
-            gemm(EPI_RESID, a);
+            a.M = M; a.N = D; a.K = D;
+            xgemm(EPI_RESID, a, true);      // + the row terms of LayerNorm 2
         }
-        rowstats();                         // LayerNorm 2, folded into fc1
-        {
+        {   // LayerNorm 2 is folded into fc1
             GemmArgs a{};
             a.A = d_xh; a.lda = D; a.W = w.fc1_wf; a.ldw = D; a.bias = w.fc1_c;
             a.rowstat = d_rstat; a.colsum = w.fc1_cs;
@@ -549,9 +559,8 @@ int Engine::run_pass(Profiler* prof) {
         {
             GemmArgs a{};
             a.A = d_mlp; a.lda = d.mlp; a.W = w.fc2_w; a.ldw = d.mlp; a.bias = w.fc2_b;
-            a.M = M; a.N = D; a.K = d.mlp; a.Xh = d_xh; a.Xl = d_xl; a.ldx = D;
-            a.cstat = l + 1 < d.L ? d_cstat : nullptr;      // the final LayerNorm reads the rows itself
-            gemm(EPI_RESID, a);
+            a.M = M; a.N = D; a.K = d.mlp;
+            xgemm(EPI_RESID, a, l + 1 < d.L);   // + the next block's LayerNorm 1 (the final LayerNorm reads the rows itself)
         }
         tap(1 + l);
     }
@@ -1755,12 +1764,27 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
         HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)N * 4, hipMemcpyHostToDevice));
         g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;
     }
+    // X-epilogues on the 256x256 kernel finalize the row terms themselves (last workgroup of each row panel)
+    DevBuf dcnt;
+    bool fused = false;
+    if (x_epi && rowstat_out) {
+        HIPCHK(dro.alloc((size_t)M * 8));
+        HIPCHK(dcnt.alloc((size_t)((M + 255) / 256 + 1) * 4));
+        HIPCHK(hipMemset(dcnt.p, 0, (size_t)((M + 255) / 256 + 1) * 4));
+        HIPCHK(hipMemset(dro.p, 0xff, (size_t)M * 8));
+        const int eff = cfg < 0 ? gemm_effective_config(g, epi) : cfg;
+        if (eff >= GEMM_CFG_256P8) {
+            g.rowstat_out = (float2*)dro.p; g.panel_cnt = (unsigned*)dcnt.p; g.ln_eps = eps;
+            fused = true;
+        }
+    }
     if (cfg < 0) HIPCHK(launch_gemm(g, epi, nullptr));
     else if (launch_gemm_cfg(g, epi, cfg, nullptr) != hipSuccess)
         return set_err(VT_ERR_INVALID_ARG, "gemm: tile configuration %d does not fit M=%d N=%d K=%d", cfg, M, N, K);
-    if (x_epi && rowstat_out) {
-        HIPCHK(dro.alloc((size_t)M * 8));
+    if (x_epi && rowstat_out && !fused)
         HIPCHK(launch_rowstat_finalize(g.cstat, (float2*)dro.p, M, N / VT_STAT_CHUNK, eps, nullptr));
+    if (fused) {      // launch it twice more: the counters must come back to zero by themselves
+        for (int rep = 0; rep < 2 && (epi == EPI_F32 || epi == EPI_F32_POS); ++rep) HIPCHK(launch_gemm_cfg(g, epi, cfg < 0 ? gemm_effective_config(g, epi) : cfg, nullptr));
     }
     HIPCHK(hipDeviceSynchronize());
     if (x_epi) {

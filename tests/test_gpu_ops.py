@@ -242,13 +242,13 @@ def test_attention(gpu, B, N, H, scale, mode):
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
                                          (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
                                          (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
-@pytest.mark.parametrize("mode", [3, 5])
+@pytest.mark.parametrize("mode", [3, 6])
 def test_attention_mode3(gpu, B, N, H, scale, mode):
     """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
     Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
     (320), more tiles than ring stages (1008), token counts that are not multiples of 16 (100, 980,
-    36: the last 16-key group is partly padding) and a ragged last query block."""
-    mode = 3
+    36: the last 16-key group is partly padding) and a ragged last query block. Mode 3: unchecked
+    first pass + careful second pass on demand; 6: the careful pass alone."""
     rng = np.random.default_rng(N + H)
     D = H * 64
     qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
@@ -262,10 +262,11 @@ def test_attention_mode3(gpu, B, N, H, scale, mode):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6])
 def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
-    sequence: the reference must move and everything accumulated before be rescaled"""
+    sequence: the reference must move and everything accumulated before be rescaled (mode 3: the
+    unchecked first pass overflows, its row-sum test fails, the careful second pass runs)"""
     rng = np.random.default_rng(77)
     B, N, H = 1, 320, 2
     D = H * 64
@@ -282,12 +283,14 @@ def test_attention_late_maximum_rescale(gpu, mode):
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4, 5])
-@pytest.mark.parametrize("level", [-20.0, -64.0, -150.0, 90.0])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("level", [-20.0, -50.0, -64.0, -150.0, 55.0, 90.0])
 def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
     p = 2^s as is (-20), below it the first step must adopt the maximum or the row would underflow
-    (-64, -150), above it the reference must move before 2^s overflows (+90)"""
+    (-64, -150), above it the reference must move before 2^s overflows (+90). Mode 3's unchecked first
+    pass accepts row sums in [2^-60, 2^60]: -50 and +55 stay inside (p = 2^s as it is, far outside the
+    +-32 window of the careful pass), -64 / -150 / +90 fail its test and take the second pass"""
     rng = np.random.default_rng(int(abs(level)))
     B, N, H = 1, 192, 1
     q = np.zeros((N, 64), np.float32)
@@ -327,7 +330,7 @@ def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
 def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
@@ -510,3 +513,27 @@ def test_folded_layernorm_in_the_qkv_epilogue(gpu, cfg):
     assert np.array_equal(qk, ref_qk)
     v = bf16_round(z[:, 2 * D:]).reshape(B, tokens, D // 64, 64).transpose(0, 2, 3, 1).reshape(-1, 64, tokens)
     assert np.array_equal(vt_[:, :, :tokens], v)
+
+
+def test_attention_second_pass_only_where_needed(gpu):
+    """mode 3 decides per workgroup (one stream and head, 128 queries): a batch in which ONE head of ONE
+    stream has scores far outside the unchecked pass's range, all others ordinary ones - every head must
+    come out right, the extreme one through the careful second pass, and identical to mode 6 (careful
+    pass alone) wherever nothing left the +-32 window"""
+    rng = np.random.default_rng(314)
+    B, N, H = 2, 320, 3
+    D = H * 64
+    qb, q = _rand_bf16(gpu, rng, (B * N, D), 0.35)
+    k = rng.standard_normal((B * N, D)).astype(np.float32)
+    k[N:, 64:128] *= 40.0                       # stream 1, head 1: |scores| up to several hundred
+    kb = _bits(gpu, k)
+    k = gpu.weights.bf16_bits_to_f32(kb)
+    vb, v = _rand_bf16(gpu, rng, (B * N, D))
+    ref = _attn_ref(q, k, v, B, N, H)
+    got3 = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=3)
+    got6 = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=6)
+    assert np.isfinite(got3).all()
+    assert np.abs(got3 - ref).max() < 0.03 * max(1.0, np.abs(ref).max())
+    calm = np.ones((B * N, D), bool)
+    calm[N:, 64:128] = False
+    assert np.array_equal(got3[calm], got6[calm])
