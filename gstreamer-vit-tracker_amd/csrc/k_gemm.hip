@@ -370,6 +370,17 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             v_tile = n0 >= 2 * p.D;
             scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;   // q * log2(e)/sqrt(64): scores in log2 units
         }
+        // folded LayerNorm: lane l31 (both halves) owns the terms of row l31 of each of its 32-row blocks;
+        // what they are made from is fetched before the main loop (k_gemm_util.hpp)
+        const bool ln = p.rowstat != nullptr || p.cstat_in != nullptr;
+        LnPart lnp[TM];
+        if (ln) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wr * WM + i * 32 + l31;
+                ln_prefetch(p, m < p.M ? m : p.M - 1, half, lnp[i]);
+            }
+        }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
             gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
@@ -377,12 +388,15 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             if constexpr (FITS) __syncthreads();
             // folded LayerNorm: y = a_r * acc + (b_r * colsum[n] + bias[n]); without one a_r = 1, b_r = 0
             // and fma(1, acc, bias) = acc + bias exactly
-            const bool ln = p.rowstat != nullptr;
+            if (ln) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mr = wr * WM + i * 32 + l31;
                 float2 rs = make_float2(1.0f, 0.0f);
-                if (ln) rs = p.rowstat[m0 + mr < p.M ? m0 + mr : p.M - 1];
+                if (ln) rs = ln_finish(p, m0 + mr < p.M ? m0 + mr : p.M - 1, lnp[i]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -442,22 +456,33 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             // folded LayerNorm: the row terms of the 16 rows per 32-row block this lane's registers hold,
             // fetched once (not per column group); rows past M read the last row, never stored
             float2 vrs[TM][4][4];
+            if (ln) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // lane l31 (both halves) works out the terms of row l31 of the 32-row block, then every lane
+                // picks those of the 16 rows its registers hold
+                float2 own = make_float2(1.0f, 0.0f);
+                if (ln) {
+                    const int m = m0 + wr * WM + i * 32 + l31;
+                    own = ln_finish(p, m < p.M ? m : p.M - 1, lnp[i]);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int m = m0 + wr * WM + i * 32 + 8 * q + 4 * half + e;
-                        vrs[i][q][e] = p.rowstat ? p.rowstat[m < p.M ? m : p.M - 1] : make_float2(1.0f, 0.0f);
+                        const int src = 8 * q + 4 * half + e;       // row of the block = lane that owns it
+                        vrs[i][q][e] = make_float2(__shfl(own.x, src), __shfl(own.y, src));
                     }
+            }
             if constexpr (FITS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int nr = wc * WN + j * 32 + l31;
-                    const bool ln = p.rowstat != nullptr;
                     const float bias = p.bias[n0 + nr], cs = ln ? p.colsum[n0 + nr] : 0.0f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -617,7 +642,12 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
         case EPI_GELU_BF16:
             if (!n128) return 2;
             return tiles128 <= 128 ? 0 : (tiles128 <= 256 ? 1 : 3);
-        case EPI_RELU_BF16: return (n128 && tiles128 >= 256) ? 3 : 2;   // head convs: N = 128
+        case EPI_RELU_BF16:             // head convs: N = 128
+            if (n128 && tiles128 >= 256) return 3;
+            // a few streams: 9-18 workgroups walk 12-18 K-tiles one after the other - a dependent chain of
+            // L2 round trips; the deepest prefetch (K-tile depth 128, ring of 3) halves it
+            if (tiles128 <= 64 && k128 && (!conv || (N % 128) == 0)) return 4;
+            return 2;
         case EPI_RESID:
             if (K >= 2048) {                       // fc2: long dependent K loop
                 if (M <= 1024 && k128) return 4;
@@ -660,7 +690,8 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
     const bool x_epi = epilogue == EPI_F32_POS || epilogue == EPI_RESID || epilogue == EPI_F32;
     if (x_epi && (!a.Xh || !a.Xl || (a.ldx & 7) || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1))))
         return hipErrorInvalidValue;
-    if (!x_epi && (!a.bias || (a.rowstat && !a.colsum))) return hipErrorInvalidValue;
+    if (!x_epi && (!a.bias || ((a.rowstat || a.cstat_in) && !a.colsum))) return hipErrorInvalidValue;
+    if (a.cstat_in && (cfg > 6 || a.rowstat || (a.K % (4 * VT_STAT_CHUNK)) != 0 || a.K > 1024)) return hipErrorInvalidValue;
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
     if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
     if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);

@@ -100,6 +100,62 @@ __device__ __forceinline__ void x_join8(const u32x4_t& hi, const u32x4_t& lo, fl
     }
 }
 
+// value of the same lane of the other wave half (lane ^ 32): v_permlane32_swap, no LDS round trip
+__device__ __forceinline__ float other_half_f32(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+// Row terms (rstd, -mean * rstd) of a folded LayerNorm for the 4-wave kernel's bf16 epilogues, where the
+// two lanes l and l + 32 hold the same row m: taken from the finalized array, or - small batches, where a
+// launch of their own would cost more than the GEMM gains - combined in the epilogue from the producing
+// X-epilogue's chunk partials, each of the two lanes taking half of the row's K / 32 chunks
+// (parallel-variance form, as launch_rowstat_finalize). The partials (up to 16 chunks per lane: K <= 1024)
+// are fetched BEFORE the main loop with inline-asm loads (hipcc would sink plain loads behind the loop and
+// wait for them one by one: measured + 4 us on a 19 us GEMM); the caller waits vmcnt(0) after the loop -
+// ln_wait - before ln_finish touches them. Both lanes of a row must take part.
+struct LnPart { u32x4_t v[8]; };
+__device__ __forceinline__ void ln_prefetch(const GemmArgs& p, int m, int half, LnPart& part) {
+    if (p.rowstat) {
+        part.v[0] = gload_b128_asm(reinterpret_cast<const char*>(p.rowstat + m) - ((m & 1) ? 8 : 0));   // 16-B aligned pair
+        return;
+    }
+    const int nl = (p.K / VT_STAT_CHUNK) >> 2;          // 16-B loads per lane: two chunks each
+    const char* src = reinterpret_cast<const char*>(p.cstat_in + (size_t)m * (p.K / VT_STAT_CHUNK)) + half * (nl * 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < nl) part.v[i] = gload_b128_asm(src + i * 16);
+}
+__device__ __forceinline__ void ln_wait(LnPart& a) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(a.v[4]), "+v"(a.v[5]),
+                 "+v"(a.v[6]), "+v"(a.v[7]) : : "memory");
+}
+__device__ __forceinline__ float2 ln_finish(const GemmArgs& p, int m, const LnPart& part) {
+    if (p.rowstat)
+        return (m & 1) ? make_float2(__uint_as_float(part.v[0][2]), __uint_as_float(part.v[0][3]))
+                       : make_float2(__uint_as_float(part.v[0][0]), __uint_as_float(part.v[0][1]));
+    const int nl = (p.K / VT_STAT_CHUNK) >> 2;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < nl) s += __uint_as_float(part.v[i][0]) + __uint_as_float(part.v[i][2]);
+    s += other_half_f32(s);
+    const float Kf = (float)p.K, mean = s / Kf;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < nl) {
+            const float d0 = __uint_as_float(part.v[i][0]) * (1.0f / VT_STAT_CHUNK) - mean;
+            const float d1 = __uint_as_float(part.v[i][2]) * (1.0f / VT_STAT_CHUNK) - mean;
+            m2 += (__uint_as_float(part.v[i][1]) + (float)VT_STAT_CHUNK * (d0 * d0)) +
+                  (__uint_as_float(part.v[i][3]) + (float)VT_STAT_CHUNK * (d1 * d1));
+        }
+    m2 += other_half_f32(m2);
+    const float rstd = 1.0f / sqrtf(m2 / Kf + p.ln_eps);
+    return make_float2(rstd, -mean * rstd);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");

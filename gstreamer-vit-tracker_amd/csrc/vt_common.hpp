@@ -90,6 +90,8 @@ struct GemmArgs {
     const float* pos; int pos_rows;     // EPI_F32_POS: [pos_rows][ldx] f32
     const float2* rowstat;        // bf16 epilogues: folded LayerNorm row terms [M] (rstd, -mean * rstd), or null
     const float* colsum;          // ... and its column sums [N]
+    const float2* cstat_in;       // 4-wave kernel only, instead of rowstat: the chunk partials [M][K / 32] of the
+                                  // X-epilogue that produced A; the epilogue combines them itself (uses ln_eps)
     bf16_t* qk; bf16_t* vt; int tokens; int npad; int D;
     int vt_perm;                  // Vt key order inside each group of 16: 0 natural, 1 attn_perm16 (attention mode 3)
     unsigned long long* dbg;      // diagnostic builds only (VT_STAMPS): per-wave cycle sums

@@ -402,7 +402,7 @@ int Engine::alloc_buffers() {
     HIPCHK(dalloc0(&d_xh, M * d.D));
     HIPCHK(dalloc0(&d_xl, M * d.D));
     HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK)));
-    HIPCHK(dalloc0(&d_rstat, M));
+    HIPCHK(dalloc0(&d_rstat, M + 1));      // + 1: the 4-wave kernel fetches row terms as aligned pairs
     HIPCHK(dalloc0(&d_panel_cnt, (M + 255) / 256 + 1));
     {   // fold LayerNorm 1 / 2 of every layer into the QKV / fc1 weights
         const size_t rows = (size_t)3 * d.D + d.mlp;
@@ -501,7 +501,11 @@ int Engine::run_pass(Profiler* prof) {
     // An X-epilogue GEMM (writes the residual pair) followed by the row terms (rstd, -mean * rstd) of the
     // LayerNorm that consumes it: finalized inside the GEMM by the last workgroup of every row panel (the
     // 256x256 kernel), else by a small launch of their own from the chunk partials
-    auto xgemm = [&](int epi, GemmArgs a, bool stats) {
+    // ... or, where the consumer runs on the 4-wave kernel (few streams), by the consumer's own epilogue:
+    // `consumer` (the GEMM with the folded LayerNorm, arguments complete but for the row terms) gets
+    // rowstat or cstat_in set accordingly.
+    auto xgemm = [&](int epi, GemmArgs a, GemmArgs* consumer, int consumer_epi) {
+        const bool stats = consumer != nullptr;
         a.Xh = d_xh; a.Xl = d_xl; a.ldx = D;
         a.cstat = stats ? d_cstat : nullptr;
         a.rowstat_out = stats ? d_rstat : nullptr;
@@ -510,10 +514,27 @@ int Engine::run_pass(Profiler* prof) {
         const bool fused = stats && gemm_finalizes_rowstat(a, epi);
         if (!fused) a.rowstat_out = nullptr;
         gemm(epi, a);
-        if (stats && !fused)
+        if (!stats) return;
+        consumer->ln_eps = d.ln_eps;
+        if (!fused && gemm_effective_config(*consumer, consumer_epi) <= 6 && consumer->K <= 1024 && consumer->K % 128 == 0) {
+            consumer->cstat_in = d_cstat;       // combined in the consumer's epilogue
+            return;
+        }
+        consumer->rowstat = d_rstat;
+        if (!fused)
             L("rowstat", 0, (double)M * (nchunk + 1) * 8,
               [&] { return launch_rowstat_finalize(d_cstat, d_rstat, M, nchunk, d.ln_eps, stream); });
     };
+    auto qkv_args = [&](int l) {
+        const LayerW& w = layers[l];
+        GemmArgs a{};
+        a.A = d_xh; a.lda = D; a.W = w.qkv_wf; a.ldw = D; a.bias = w.qkv_c; a.colsum = w.qkv_cs;
+        a.M = M; a.N = 3 * D; a.K = D;
+        a.qk = d_qk; a.vt = d_vt; a.tokens = d.ntok; a.npad = d.npad; a.D = D;
+        a.vt_perm = attention_vt_perm(attention_pick_mode(d.ntok, d.npad));   // layout the attention kernel reads
+        return a;
+    };
+    GemmArgs qkv = qkv_args(0);             // LayerNorm 1 is folded into the QKV GEMM
 
     // K1: crop + resize + normalise the search window of every stream -> patch rows
     L("preproc_search", 0, (double)B * (d.S * d.S * 3 * 2 + 1.5 * d.S * d.S),
@@ -526,20 +547,12 @@ int Engine::run_pass(Profiler* prof) {
         a.bias = (const float*)find("patch_b")->ptr;
         a.M = M; a.N = D; a.K = d.kpad;
         a.pos = (const float*)find("pos")->ptr; a.pos_rows = d.ntok;
-        xgemm(EPI_F32_POS, a, true);        // + the row terms of block 0's LayerNorm 1
+        xgemm(EPI_F32_POS, a, &qkv, EPI_QKV);       // + the row terms of block 0's LayerNorm 1
     }
     tap(0);
     for (int l = 0; l < d.L; ++l) {
         const LayerW& w = layers[l];
-        {   // LayerNorm 1 is folded into the QKV GEMM
-            GemmArgs a{};
-            a.A = d_xh; a.lda = D; a.W = w.qkv_wf; a.ldw = D; a.bias = w.qkv_c;
-            a.rowstat = d_rstat; a.colsum = w.qkv_cs;
-            a.M = M; a.N = 3 * D; a.K = D;
-            a.qk = d_qk; a.vt = d_vt; a.tokens = d.ntok; a.npad = d.npad; a.D = D;
-            a.vt_perm = attention_vt_perm(attention_pick_mode(d.ntok, d.npad));   // layout the attention kernel reads
-            gemm(EPI_QKV, a);
-        }
+        gemm(EPI_QKV, qkv);
         L("attention", 4.0 * B * (double)d.ntok * d.ntok * D, (double)M * D * 8, [&] {
             return launch_attention(d_qk, d_vt, d_attn, B, d.ntok, d.H, d.npad, stream);
         });
@@ -547,20 +560,22 @@ int Engine::run_pass(Profiler* prof) {
             GemmArgs a{};
             a.A = d_attn; a.lda = D; a.W = w.proj_w; a.ldw = D; a.bias = w.proj_b;
             a.M = M; a.N = D; a.K = D;
-            xgemm(EPI_RESID, a, true);      // + the row terms of LayerNorm 2
-        }
-        {   // LayerNorm 2 is folded into fc1
-            GemmArgs a{};
-            a.A = d_xh; a.lda = D; a.W = w.fc1_wf; a.ldw = D; a.bias = w.fc1_c;
-            a.rowstat = d_rstat; a.colsum = w.fc1_cs;
-            a.M = M; a.N = d.mlp; a.K = D; a.Cb = d_mlp; a.ldcb = d.mlp;
-            gemm(EPI_GELU_BF16, a);
+            GemmArgs f{};                   // LayerNorm 2 is folded into fc1
+            f.A = d_xh; f.lda = D; f.W = w.fc1_wf; f.ldw = D; f.bias = w.fc1_c; f.colsum = w.fc1_cs;
+            f.M = M; f.N = d.mlp; f.K = D; f.Cb = d_mlp; f.ldcb = d.mlp;
+            xgemm(EPI_RESID, a, &f, EPI_GELU_BF16);      // + the row terms of LayerNorm 2
+            gemm(EPI_GELU_BF16, f);
         }
         {
             GemmArgs a{};
             a.A = d_mlp; a.lda = d.mlp; a.W = w.fc2_w; a.ldw = d.mlp; a.bias = w.fc2_b;
             a.M = M; a.N = D; a.K = d.mlp;
-            xgemm(EPI_RESID, a, l + 1 < d.L);   // + the next block's LayerNorm 1 (the final LayerNorm reads the rows itself)
+            if (l + 1 < d.L) {              // + the next block's LayerNorm 1 (the final LayerNorm reads the rows itself)
+                qkv = qkv_args(l + 1);
+                xgemm(EPI_RESID, a, &qkv, EPI_QKV);
+            } else {
+                xgemm(EPI_RESID, a, nullptr, 0);
+            }
         }
         tap(1 + l);
     }
@@ -1759,7 +1774,7 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
         g.cstat = (float2*)dcst.p;
     } else if (rowstat_in) {
         if (!colsum) return set_err(VT_ERR_INVALID_ARG, "gemm: rowstat without colsum");
-        HIPCHK(drs.alloc((size_t)M * 8)); HIPCHK(dcs.alloc((size_t)N * 4));
+        HIPCHK(drs.alloc((size_t)M * 8 + 16)); HIPCHK(dcs.alloc((size_t)N * 4));
         HIPCHK(hipMemcpy(drs.p, rowstat_in, (size_t)M * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)N * 4, hipMemcpyHostToDevice));
         g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;
@@ -1813,7 +1828,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     DevBuf da, dw, db, dc, dcb, dvt, dxl, dcst, drs;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
     HIPCHK(dc.alloc((size_t)M * N * 4)); HIPCHK(dcb.alloc((size_t)M * N * 2)); HIPCHK(dxl.alloc((size_t)M * N * 2));
-    HIPCHK(dcst.alloc((size_t)M * (N / VT_STAT_CHUNK) * 8)); HIPCHK(drs.alloc((size_t)M * 8));
+    HIPCHK(dcst.alloc((size_t)M * (N / VT_STAT_CHUNK) * 8)); HIPCHK(drs.alloc((size_t)M * 8 + 16));
     HIPCHK(dvt.alloc((size_t)(N / 64 + 1) * 64 * npad * 2));
     std::vector<bf16_t> ha((size_t)M * K), hw((size_t)N * K);
     uint32_t seed = 12345u;
@@ -1897,7 +1912,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
     DevBuf drs, dcs;
     if (rowstat_in) {              // folded LayerNorm: [M][2] row terms, [3D] column sums
         if (!colsum) return set_err(VT_ERR_INVALID_ARG, "qkv: rowstat without colsum");
-        HIPCHK(drs.alloc((size_t)M * 8)); HIPCHK(dcs.alloc((size_t)3 * D * 4));
+        HIPCHK(drs.alloc((size_t)M * 8 + 16)); HIPCHK(dcs.alloc((size_t)3 * D * 4));
         HIPCHK(hipMemcpy(drs.p, rowstat_in, (size_t)M * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)3 * D * 4, hipMemcpyHostToDevice));
         g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;

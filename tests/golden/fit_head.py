@@ -178,7 +178,7 @@ def fit(cfg_name: str, n_train: int, steps: int, out_path: str | None = None):
     return asset
 
 
-def make_samples_gpu(cfg, n: int, seed: int, w=960, h=540, bs=32):
+def make_samples_gpu(cfg, n: int, seed: int, w=960, h=540, bs=32, sq_range=(36, 120)):
     """features from the HIP path: for each sample the template comes from the true box, the search
     window from a jittered previous box (vt_group_set_state_box), feat = final-LN tap"""
     wpath = vt.weights.ensure_weights(cfg.name, use_asset=False)
@@ -193,8 +193,8 @@ def make_samples_gpu(cfg, n: int, seed: int, w=960, h=540, bs=32):
         host = np.empty((bs, fbytes), np.uint8)
         gts, prevs = [], []
         for i in range(bs):
-            sw = int(rng.integers(36, 120))
-            sh = sw if rng.random() < 0.6 else int(rng.integers(36, 120))
+            sw = int(rng.integers(*sq_range))
+            sh = sw if rng.random() < 0.6 else int(rng.integers(*sq_range))
             x, y = int(rng.integers(0, w - sw)), int(rng.integers(0, h - sh))
             yy = bgs[int(rng.integers(8))].copy()
             yy[y:y + sh, x:x + sw] = (200 + rng.integers(-12, 13, size=(sh, sw))).astype(np.uint8)
@@ -271,11 +271,16 @@ def export_head(head, cfg, out_dir=None):
     return asset
 
 
-def fit_gpu(cfg_name: str, n_train: int, steps: int, out_dir: str, batch: int = 256):
+def fit_gpu(cfg_name: str, n_train: int, steps: int, out_dir: str, batch: int = 256, noise: float = 0.0,
+            frame=(960, 540), sq_range=(36, 120)):
+    """noise > 0: Gaussian noise of that standard deviation on every feature element of every step. The
+    two bf16 implementations that the parity tests compare differ by about 4e-3 of the feature maximum
+    (a few 1e-3 per element, DESIGN.md section 5 / tools/arbiter.py); a head fitted on clean features
+    only may turn that into a pixel of box difference, one that has seen such perturbations does not."""
     cfg = vt.weights.get_config(cfg_name)
     torch.manual_seed(0)
     t0 = time.time()
-    feats, tg = make_samples_gpu(cfg, n_train, seed=1234)
+    feats, tg = make_samples_gpu(cfg, n_train, seed=1234, w=frame[0], h=frame[1], sq_range=sq_range)
     g, d, c = cfg.grid_s, cfg.dim, cfg.head_ch
     print(f"[{cfg.name}] {n_train} samples of HIP features in {time.time() - t0:.1f}s", flush=True)
     tgt = torch.from_numpy(tg).cuda()
@@ -291,6 +296,8 @@ def fit_gpu(cfg_name: str, n_train: int, steps: int, out_dir: str, batch: int = 
     for step in range(steps):
         idx = torch.randint(0, n_train, (min(batch, n_train),), device="cuda", generator=gen)
         x = feats[idx].float().reshape(-1, g, g, d)
+        if noise > 0:
+            x = x + noise * torch.randn(x.shape, device="cuda", generator=gen)
         heat = torch.exp(-((gx[None, None, :] - cx[idx, None, None]) ** 2 +
                            (gx[None, :, None] - cy[idx, None, None]) ** 2) / (2 * 0.65 ** 2))
         loss, sl, rl = head_loss(head(x), heat, inside[idx], cx[idx], cy[idx], ix[idx], iy[idx],
@@ -365,13 +372,18 @@ if __name__ == "__main__":
     ap.add_argument("--samples", type=int, default=4000)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--out", default=None, help="directory for the .npz (default: the package's assets/)")
+    ap.add_argument("--noise", type=float, default=0.0, help="--gpu: std of Gaussian feature noise per step")
+    ap.add_argument("--frame", default="960x540", help="--gpu: size of the synthetic training frames")
+    ap.add_argument("--squares", default="36-120", help="--gpu: range of target sizes in pixels")
     a = ap.parse_args()
     torch.set_num_threads(int(os.environ.get("FIT_THREADS", "8")))
     for nme in a.configs:
         if nme.startswith("validate:"):
             validate(nme.split(":", 1)[1])
         elif a.gpu:
-            fit_gpu(nme, a.samples, a.steps, a.out)
+            fw_, fh_ = (int(v) for v in a.frame.split("x"))
+            lo_, hi_ = (int(v) for v in a.squares.split("-"))
+            fit_gpu(nme, a.samples, a.steps, a.out, noise=a.noise, frame=(fw_, fh_), sq_range=(lo_, hi_))
         else:
             cfgs = {"tiny": (256, 500), "cfg2": (160, 400), "cfg3": (128, 1000), "cfg5": (64, 700)}
             n, st = cfgs.get(nme, (128, 400))

@@ -143,11 +143,14 @@ def test_network_stage_taps(gpu, oracle, cfg):
     g.enable_taps(False)
 
 
-def test_network_stage_taps_on_the_30_stream_engine(gpu, oracle, weights_cfg3):
+@pytest.mark.parametrize("B", [30, 8])
+def test_network_stage_taps_on_the_30_stream_engine(gpu, oracle, weights_cfg3, B):
     """the same per-block comparison on the benchmark's shapes: one engine of 30 cfg3 streams runs every
-    encoder GEMM on the 256x256 kernels (persistent for QKV / fc1); the first and the last stream's
-    residual streams after every block, features and head logits against one oracle forward"""
-    B = 30
+    encoder GEMM on the 256x256 kernels (persistent for QKV / fc1; the row terms of the folded LayerNorms
+    finalized by the last workgroup of each row panel); the first and the last stream's residual streams
+    after every block, features and head logits against one oracle forward. 8 streams: the mixed case -
+    proj / fc2 on the 4-wave kernel, QKV / fc1 on the 256x256 one, row terms by the finalize launch
+    (a single tracker, test above: everything on the 4-wave kernel, row terms combined in the consumer)"""
     sc = gpu.synth.MovingSquare(640, 480, 64, seed=2)
     buf, box = sc.frame_nv12(0), sc.gt_box(0)
     grp = gpu.Group(weights_cfg3, n_streams=B)
