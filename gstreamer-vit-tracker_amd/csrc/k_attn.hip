@@ -502,7 +502,14 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     AT3_STAGE_TILE(0, 0)
     if (AHEAD > 1 && nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
     int sbase = 0;                       // LDS offset of the stage holding tile kt
-    for (int kt = 0; kt < nt; ++kt) {
+    // The unchecked pass does not compute what is thrown away: a wave whose 32 queries lie past the last
+    // token (the fourth wave of a stream's last workgroup at 720 tokens) only stages its share of the tiles,
+    // and when at most 32 keys of the last tile exist (720 = 11 x 64 + 16) that tile is a half step after
+    // the loop: one QK chain, 16 exponentials, 6 of the 12 P.V MFMAs (4 % of the kernel's work each).
+    const bool active = CAREFUL || qb < nqb;
+    const bool half_last = !CAREFUL && (tokens & 63) != 0 && (tokens & 63) <= 32;
+    const int nfull = half_last ? nt - 1 : nt;
+    for (int kt = 0; kt < nfull; ++kt) {
         if (AHEAD > 1 && kt + 1 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
         // every wave's pieces of tile kt have landed, and every wave is done with tile kt-1,
         // whose stage tile kt+AHEAD overwrites
@@ -512,6 +519,10 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             int s2base = sbase + AHEAD * AT3_STAGE;
             s2base = s2base >= NS * AT3_STAGE ? s2base - NS * AT3_STAGE : s2base;
             AT3_STAGE_TILE(kt + AHEAD, s2base)
+        }
+        if (!active) {                    // wave-uniform
+            sbase = sbase + AT3_STAGE >= NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
+            continue;
         }
         const char* st = smem + sbase;
         const char* p0 = st + fa0; const char* p1 = st + fa1;
@@ -726,12 +737,46 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         }   // ORD != 2
         sbase = sbase + AT3_STAGE >= NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
     }
+    if constexpr (!CAREFUL) {
+        if (half_last) {                  // block-uniform: keys nt*64-64 .. tokens-1 (1 .. 32 of them)
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) {
+                const char* st = smem + sbase;
+                const char* p0 = st + fa0; const char* p1 = st + fa1;
+                const char* p2 = st + fa2; const char* p3 = st + fa3;
+                const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                                       0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                f32x16_t sh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 0), qf[0], zero, 0, 0, 0);
+                sh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 0), qf[1], sh, 0, 0, 0);
+                sh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p2, 0), qf[2], sh, 0, 0, 0);
+                sh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p3, 0), qf[3], sh, 0, 0, 0);
+                const int key0 = (nt - 1) * 64 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) sh[r] = -INFINITY;
+                union { uint32_t u[4]; bf16x8_t v; } c0, c1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(sh[2 * e]), __builtin_amdgcn_exp2f(sh[2 * e + 1]));
+                    c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(sh[8 + 2 * e]), __builtin_amdgcn_exp2f(sh[8 + 2 * e + 1]));
+                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 8192), c0.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 12288), c0.v, o1, 0, 0, 0);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c0.v, osum, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 8192), c1.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 12288), c1.v, o1, 0, 0, 0);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c1.v, osum, 0, 0, 0);
+            }
+        }
+    }
     __syncthreads();                      // every wave is done reading the ring
     if constexpr (!careful) {
         // did every query of the workgroup stay in range? (the barriers of a pass are workgroup-wide, so
         // the four waves repeat together or not at all; the flags live in the dead ring)
         const float l = osum[0];
-        const bool bad = !(l >= 0x1p-60f && l <= 0x1p60f);
+        const bool bad = active && !(l >= 0x1p-60f && l <= 0x1p60f);
         const unsigned long long bm = __ballot(bad);
         int* flag = reinterpret_cast<int*>(smem);
         if (lane == 0) flag[wave] = bm != 0ull;

@@ -636,12 +636,14 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
     // is worth 0.5 us on the K = 768 shapes and 2-3 us on fc2.
     const bool k128 = (K % 128) == 0;
     switch (epilogue) {
+        // (re-measured in round 3 with the folded-LayerNorm epilogues, profiles/r03_small_batch_gemm_sweep.txt:
+        // one stream QKV 5: 9.5 us, fc1 2: 13.4 (1: 16.6); two streams QKV 2: 14.8 (1: 16.6), fc1 3: 22.3)
         case EPI_QKV:
             if (!n128) return 2;
-            return tiles128 <= 128 ? (k128 ? 5 : 0) : (tiles128 <= 256 ? 1 : 3);
+            return tiles128 <= 128 ? (k128 ? 5 : 0) : (tiles128 <= 256 ? 2 : 3);
         case EPI_GELU_BF16:
             if (!n128) return 2;
-            return tiles128 <= 128 ? 0 : (tiles128 <= 256 ? 1 : 3);
+            return tiles128 <= 128 ? 0 : (tiles128 <= 192 ? 2 : (tiles128 <= 256 ? 1 : 3));
         case EPI_RELU_BF16:             // head convs: N = 128
             if (n128 && tiles128 >= 256) return 3;
             // a few streams: 9-18 workgroups walk 12-18 K-tiles one after the other - a dependent chain of

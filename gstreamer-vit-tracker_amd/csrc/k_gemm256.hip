@@ -810,8 +810,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     const uint32_t b_k0 = (uint32_t)(2 * G256_HALF + (wc * 32 + l15) * 128 + ((q ^ sw) << 4));
     const int nk = p.K >> 6;
 
+    // Which tiles of the column-group-major list a workgroup walks: 32 per XCD and round. (Round 3 measured
+    // and dropped the alternative of an XCD OWNING a column group and a quarter of its tiles for the whole
+    // launch - W panels resident in its L2, every A panel fetched by one XCD per group: fc1 at 30 streams
+    // 105.7 us against 100.5 with this dealing, ViT-L fc1 283 against 286: profiles/r03_tile_order_ab.txt.)
     int seq = xcd * 32 + slot;                 // round 0: chunk xcd
     const int seq_step = 8 * 32;               // next round: chunk + 8
+    const int seq_end = tiles;
     (void)per_round;
     int m0 = 0, n0 = 0;
     bool after16 = false;
@@ -822,12 +827,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
 #else
 #define G256P_T(v)
 #endif
-    if (slot < 32 && seq < tiles) {
+    if (slot < 32 && seq < seq_end) {
         G256P_TILE(seq, m0, n0)
         G256P_OFFSETS(m0, n0)
         G256P_PROLOGUE()
     }
-    for (; slot < 32 && seq < tiles; seq += seq_step) {
+    for (; slot < 32 && seq < seq_end; seq += seq_step) {
         acc256_t acc;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         // every wave has finished reading the ring
         const int tm0 = m0, tn0 = n0;                 // the tile whose accumulators we hold
         const int nseq = seq + seq_step;
-        const bool more = nseq < tiles;
+        const bool more = nseq < seq_end;
         after16 = false;
         if (more) { G256P_TILE(nseq, m0, n0) }
         if (!v_tile) {
