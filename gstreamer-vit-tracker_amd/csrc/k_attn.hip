@@ -407,6 +407,18 @@ __global__ __launch_bounds__(256, 2) void attention_lds_kernel(const bf16_t* __r
 #define ATT_WIN 32.0f          // half-width of the score window inside which the reference stays put
 #define AT3_NS 3
 
+// acc + the sum of the 8 bf16 values of a P fragment: four v_dot2c_f32_bf16 against (1, 1) - exact products,
+// float32 accumulation, i.e. the sum of the ROUNDED probabilities the P.V product uses
+__device__ __forceinline__ float sum_p8(const bf16x8_t& p, float acc) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    union { bf16x8_t v; uint32_t u[4]; } c;
+    c.v = p;
+    const bf2_t one2 = __builtin_bit_cast(bf2_t, 0x3f803f80u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, c.u[e]), one2, acc, false);
+    return acc;
+}
+
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
 }
@@ -424,7 +436,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // +-32 window the two passes are the same arithmetic. Two inlined copies, one after the other, rather
 // than a loop with a flag: with a back edge hipcc keeps the whole set-up live (190 VGPRs, 98 spilled
 // SGPRs: two waves per SIMD instead of three).
-template <int ORD, int NS, bool CAREFUL>
+// SUMV (ORD 0): the row sums are kept on the vector ALU (sum_p8: 16 v_dot2c per 64-key step and lane, the
+// two lane halves added once at the end) instead of a third P.V MFMA against a tile of ones - 4 of the 20
+// MFMAs of a step; without the running-maximum bookkeeping the step is bound by the matrix pipe, not by
+// vector issue (profiles/r03_attention_ab.txt).
+template <int ORD, int NS, bool CAREFUL, bool SUMV>
 __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                          bf16_t* __restrict__ out, int tokens, int H, int npad, int tid, int block) {
     const int lane = tid & 63;
@@ -494,6 +510,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     // has been accumulated, only when a maximum leaves that window (upwards in any step; downwards
     // in the first step, so that a row of uniformly tiny scores does not underflow).
     float m_run = 0.0f;
+    float lsum = 0.0f;                   // SUMV: this lane's share of its query's row sum
     bool shifted = false;                // wave-uniform: some lane's m_run != 0
     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
     constexpr int AHEAD = NS - 1;        // tiles in flight beyond the one being computed
@@ -640,6 +657,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
                 if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
         }                                                                                          \
+        if constexpr (careful) {                                                                   \
         if (shifted) {                                                                             \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
         }                                                                                          \
@@ -653,10 +671,12 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             m_run += dm;                                                                           \
             shifted = true;                                                                        \
             osum[0] *= alpha;                                                                      \
+            lsum *= alpha;                                                                         \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
                 o0[r] *= alpha; o1[r] *= alpha;                                                    \
                 S[r] -= dm;                                                                        \
             }                                                                                      \
+        }                                                                                          \
         }                                                                                          \
         bf16x8_t pa, pb;                                                                           \
         {                                                                                          \
@@ -669,10 +689,12 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         }                                                                                          \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0], pa, o0, 0, 0, 0);                    \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0], pa, o1, 0, 0, 0);                    \
-        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);                   \
+        if constexpr (SUMV) lsum = sum_p8(pa, lsum);                                               \
+        else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);              \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0 + 1], pb, o0, 0, 0, 0);                \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0 + 1], pb, o1, 0, 0, 0);                \
-        osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);                   \
+        if constexpr (SUMV) lsum = sum_p8(pb, lsum);                                               \
+        else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);              \
     }
             AT3_HALF(s0, 0, true, 0)
             AT3_HALF(s1, 32, false, 2)
@@ -708,6 +730,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 m_run += dm;
                 shifted = true;
                 osum[0] *= alpha;
+                lsum *= alpha;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o0[r] *= alpha; o1[r] *= alpha;
@@ -731,7 +754,8 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
-                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
+                if constexpr (SUMV) lsum = sum_p8(pf[g], lsum);
+                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
             }
         }
         }   // ORD != 2
@@ -764,10 +788,12 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 8192), c0.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 12288), c0.v, o1, 0, 0, 0);
-                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c0.v, osum, 0, 0, 0);
+                if constexpr (SUMV) lsum = sum_p8(c0.v, lsum);
+                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c0.v, osum, 0, 0, 0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 8192), c1.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 12288), c1.v, o1, 0, 0, 0);
-                osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c1.v, osum, 0, 0, 0);
+                if constexpr (SUMV) lsum = sum_p8(c1.v, lsum);
+                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c1.v, osum, 0, 0, 0);
             }
         }
     }
@@ -775,7 +801,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     if constexpr (!careful) {
         // did every query of the workgroup stay in range? (the barriers of a pass are workgroup-wide, so
         // the four waves repeat together or not at all; the flags live in the dead ring)
-        const float l = osum[0];
+        const float l = SUMV ? xhalf_sum(lsum) : osum[0];
         const bool bad = active && !(l >= 0x1p-60f && l <= 0x1p60f);
         const unsigned long long bm = __ballot(bad);
         int* flag = reinterpret_cast<int*>(smem);
@@ -785,7 +811,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         __syncthreads();                  // flags read before anything overwrites them
         if (any) return true;
     }
-    const float l_run = osum[0];
+    const float l_run = SUMV ? xhalf_sum(lsum) : osum[0];
 
     // ---- epilogue: O^T (d on registers, query on lanes) -> LDS [32 q][128 B] per wave -> rows ----
     {
@@ -815,7 +841,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     return false;
 }
 
-template <int ORD, int NS, int WPS>
+template <int ORD, int NS, int WPS, bool SUMV = false>
 __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
@@ -829,8 +855,8 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
         const int k = (int)(blockIdx.x / 256u) % 3;
         for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
-    if constexpr (ORD == 0) {
-        if (at3_pass<0, NS, false>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
+    if constexpr (ORD == 0 || ORD == 1) {
+        if (at3_pass<ORD, NS, false, SUMV>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
             __syncthreads();
             // the (rare) second pass rebuilds every address from opaque copies of its inputs: if the
             // compiler could see that the two inlined passes compute the same values it would keep the
@@ -839,10 +865,10 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
             const bf16_t* q2 = qk; const bf16_t* v2 = vt; bf16_t* o2 = out;
             asm volatile("" : "+v"(t2));
             asm volatile("" : "+s"(b2), "+s"(tk), "+s"(hh), "+s"(np2), "+s"(q2), "+s"(v2), "+s"(o2));
-            at3_pass<0, NS, true>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
+            at3_pass<ORD, NS, true, SUMV>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
         }
     } else {
-        at3_pass<ORD, NS, true>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
+        at3_pass<ORD, NS, true, false>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
     }
 }
 
@@ -880,13 +906,16 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
     } else if (mode == 3) {
         // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc
         // then spills (100 B of scratch) sits in the rare second pass only (checked in the ISA)
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, true>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 7) {               // tuning only: mode 3 with the row sums from a P.V MFMA against ones
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, false>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 6) {               // tuning only: mode 3 without the unchecked first pass (round 2's kernel)
         hipLaunchKernelGGL((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
-        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 3, true>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 5) {               // 4 workgroups per CU: 2-stage ring, sequential halves in <= 128 registers
         hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,

@@ -229,7 +229,7 @@ def make_samples_gpu(cfg, n: int, seed: int, w=960, h=540, bs=32, sq_range=(36, 
     return feats, targets
 
 
-def head_loss(out, heat, inside, cx, cy, ix, iy, tgt, g):
+def head_loss(out, heat, inside, cx, cy, ix, iy, tgt, g, size_weight=1.0):
     ar = torch.arange(out.shape[0], device=out.device)
     score_loss = F.binary_cross_entropy_with_logits(out[:, 0], heat * inside[:, None, None])
     loss_reg = 0.0
@@ -242,9 +242,9 @@ def head_loss(out, heat, inside, cx, cy, ix, iy, tgt, g):
             wgt = inside * (1.0 if (dx == 0 and dy == 0) else 0.5)
             loss_reg = loss_reg + (
                 F.l1_loss(3 * torch.sigmoid(q[:, 1]) - 1, tx, reduction="none") * wgt).mean() + (
-                F.l1_loss(3 * torch.sigmoid(q[:, 2]) - 1, ty, reduction="none") * wgt).mean() + (
+                F.l1_loss(3 * torch.sigmoid(q[:, 2]) - 1, ty, reduction="none") * wgt).mean() + size_weight * ((
                 F.l1_loss(torch.sigmoid(q[:, 3]), tgt[:, 2], reduction="none") * wgt).mean() + (
-                F.l1_loss(torch.sigmoid(q[:, 4]), tgt[:, 3], reduction="none") * wgt).mean()
+                F.l1_loss(torch.sigmoid(q[:, 4]), tgt[:, 3], reduction="none") * wgt).mean())
     return 20.0 * score_loss + loss_reg, score_loss, loss_reg
 
 
@@ -272,7 +272,7 @@ def export_head(head, cfg, out_dir=None):
 
 
 def fit_gpu(cfg_name: str, n_train: int, steps: int, out_dir: str, batch: int = 256, noise: float = 0.0,
-            frame=(960, 540), sq_range=(36, 120)):
+            frame=(960, 540), sq_range=(36, 120), size_weight: float = 1.0):
     """noise > 0: Gaussian noise of that standard deviation on every feature element of every step. The
     two bf16 implementations that the parity tests compare differ by about 4e-3 of the feature maximum
     (a few 1e-3 per element, DESIGN.md section 5 / tools/arbiter.py); a head fitted on clean features
@@ -301,7 +301,7 @@ def fit_gpu(cfg_name: str, n_train: int, steps: int, out_dir: str, batch: int = 
         heat = torch.exp(-((gx[None, None, :] - cx[idx, None, None]) ** 2 +
                            (gx[None, :, None] - cy[idx, None, None]) ** 2) / (2 * 0.65 ** 2))
         loss, sl, rl = head_loss(head(x), heat, inside[idx], cx[idx], cy[idx], ix[idx], iy[idx],
-                                 tgt[idx], g)
+                                 tgt[idx], g, size_weight)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -320,7 +320,8 @@ def validate_gpu(cfg, asset, frames: int = 200):
     w, h, sq = (3840, 2160, 160) if cfg.patch == 14 else ((1920, 1080, 64) if big else (640, 480, 64))
     sc = vt.synth.MovingSquare(w, h, sq, seed=0)
     trk = vt.VitTrack(wpath)
-    ious, scores = [], []
+    ious, scores, errs = [], [], []
+    g = trk.as_group()
     for t in range(frames):
         fr = vt.NV12Frame(sc.frame_nv12(t), w, h)
         if t == 0:
@@ -332,8 +333,13 @@ def validate_gpu(cfg, asset, frames: int = 200):
         ih = max(0, min(gy + gh, by + bh) - max(gy, by))
         ious.append(iw * ih / (gw * gh + bw * bh - iw * ih))
         scores.append(r.score)
+        fb = g.read_state()["last_fbox"]
+        errs.append([fb[0] + fb[2] / 2 - (gx + gw / 2), fb[1] + fb[3] / 2 - (gy + gh / 2), fb[2] - gw, fb[3] - gh])
+    e = np.array(errs)
     print(f"[{cfg.name}] HIP closed loop {frames} frames: IoU vs GT min {min(ious):.3f} mean "
-          f"{np.mean(ious):.3f}; score min {min(scores):.3f}", flush=True)
+          f"{np.mean(ious):.3f}; score min {min(scores):.3f}; float box error vs GT (cx, cy, w, h) px: mean "
+          f"{np.round(e.mean(axis=0), 2).tolist()} std {np.round(e.std(axis=0), 2).tolist()} max |.| "
+          f"{np.round(np.abs(e).max(axis=0), 2).tolist()}", flush=True)
 
 
 def validate(cfg_name: str, frames: int = 40):
@@ -375,6 +381,8 @@ if __name__ == "__main__":
     ap.add_argument("--noise", type=float, default=0.0, help="--gpu: std of Gaussian feature noise per step")
     ap.add_argument("--frame", default="960x540", help="--gpu: size of the synthetic training frames")
     ap.add_argument("--squares", default="36-120", help="--gpu: range of target sizes in pixels")
+    ap.add_argument("--size-weight", type=float, default=1.0, help="--gpu: weight of the two size terms of the loss")
+    ap.add_argument("--batch", type=int, default=256)
     a = ap.parse_args()
     torch.set_num_threads(int(os.environ.get("FIT_THREADS", "8")))
     for nme in a.configs:
@@ -383,7 +391,8 @@ if __name__ == "__main__":
         elif a.gpu:
             fw_, fh_ = (int(v) for v in a.frame.split("x"))
             lo_, hi_ = (int(v) for v in a.squares.split("-"))
-            fit_gpu(nme, a.samples, a.steps, a.out, noise=a.noise, frame=(fw_, fh_), sq_range=(lo_, hi_))
+            fit_gpu(nme, a.samples, a.steps, a.out, batch=a.batch, noise=a.noise, frame=(fw_, fh_), sq_range=(lo_, hi_),
+                    size_weight=a.size_weight)
         else:
             cfgs = {"tiny": (256, 500), "cfg2": (160, 400), "cfg3": (128, 1000), "cfg5": (64, 700)}
             n, st = cfgs.get(nme, (128, 400))

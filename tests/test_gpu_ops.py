@@ -262,7 +262,7 @@ def test_attention_mode3(gpu, B, N, H, scale, mode):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6, 7])
 def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
     sequence: the reference must move and everything accumulated before be rescaled (mode 3: the
@@ -283,7 +283,7 @@ def test_attention_late_maximum_rescale(gpu, mode):
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("level", [-20.0, -50.0, -64.0, -150.0, 55.0, 90.0])
 def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
@@ -330,7 +330,7 @@ def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
@@ -536,4 +536,7 @@ def test_attention_second_pass_only_where_needed(gpu):
     assert np.abs(got3 - ref).max() < 0.03 * max(1.0, np.abs(ref).max())
     calm = np.ones((B * N, D), bool)
     calm[N:, 64:128] = False
-    assert np.array_equal(got3[calm], got6[calm])
+    # mode 6 sums the probabilities on the matrix pipe, mode 3 on the vector ALU (float32, other order): the
+    # bf16 outputs may differ by one unit in the last place, not more
+    assert np.all(np.abs(got3[calm] - got6[calm]) <= np.abs(got6[calm]) * 2.0 ** -7 + 1e-6)
+    assert np.array_equal(got3, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=3))      # run-to-run identical

@@ -2,7 +2,7 @@
 trajectories (tests/golden/traj_*.npz, forced_*.npz; generator tests/golden/make_traj.py), so the GPU
 run does not pay seconds of CPU oracle per frame.
 
-  * closed loop, 300 frames on the headline config cfg3 (and cfg2), 60 on cfg5 (4K, ViT-L/14):
+  * closed loop, 300 frames on the headline config cfg3, on cfg2 and on cfg5 (4K, ViT-L/14):
     per-frame |dx|,|dy|,|dw|,|dh| <= 1 px, equal success flags, |dscore| < 0.03, and the IoU report:
     SURVEY.md section 8(d) wrote "IoU >= 0.99 per frame", which +-1 px on a 64-px box cannot
     guarantee (one coordinate off by one is IoU 0.969, two are 0.94): the test asserts what both
@@ -50,18 +50,19 @@ def _clip(gpu, fx):
                                   seed=int(fx["seed"]))
 
 
-# Bars per fixture. cfg2 / cfg3 (1080p, 64-px target: the search crop is 256 px wide): +-1 px, the
-# north_star's bar. cfg5 (4K, 160-px target, ViT-L/14 with twice the layers): the crop is 640 px wide,
-# so one pixel is 2.5x finer in the network's normalised units, and the residual-stream deviation
-# between the two bf16 implementations is twice cfg3's (tools/diag_taps.py: 2.2e-3 vs 1.1e-3 of max
-# after the last block): +-2 px there is the same normalised agreement as +-0.8 px at 1080p. Measured
-# in round 2: cfg3 300 frames max 1 px (297 identical boxes), cfg5 60 frames max 2 px (36 identical).
+# Bars per fixture: the north_star's - every one of the first 300 frames within +-1 px - on all three
+# configurations. (Round 2 held the 4K ViT-L/14 clip to +-2 px over 60 frames. Round 3 arbitrated: against
+# an un-quantised float64 formulation both bf16 implementations are equally far from the truth at every
+# stage (tools/arbiter.py, profiles/r03_arbiter_cfg5.txt: residual stream 2.2e-3 both, decoded float box
+# 0.03 px both) - bf16 noise, not a kernel; what turned it into 2 px in closed loop was the head's
+# conditioning on 160-px targets, so the cfg5 head was refitted on targets of that size with feature noise.)
 BARS = {"traj_cfg3_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg2_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
-        "traj_cfg5_60.npz": dict(px=2, min_iou=0.95, mean_iou=0.99)}
+        "traj_cfg5_300.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
+FIXTURES = ["traj_cfg3_300.npz", "traj_cfg2_300.npz", "traj_cfg5_300.npz"]
 
 
-@pytest.mark.parametrize("name", ["traj_cfg3_300.npz", "traj_cfg2_300.npz", "traj_cfg5_60.npz"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
     fx = _fixture(name)
     bar = BARS[name]
@@ -107,7 +108,7 @@ def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
     assert gt_iou.min() > 0.5, "the oracle lost the target: the parity above would be vacuous"
 
 
-@pytest.mark.parametrize("name", ["traj_cfg3_300.npz", "traj_cfg2_300.npz", "traj_cfg5_60.npz"])
+@pytest.mark.parametrize("name", FIXTURES)
 def test_closed_loop_through_the_batched_large_tile_path(gpu, name, capsys):
     """The same full-length gate on the path bench.py times: ONE engine of as many streams as
     vt_recommended_streams says (cfg3: 30 streams, M = 21,600 rows: every encoder GEMM on the 256x256
