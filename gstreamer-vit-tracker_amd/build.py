@@ -55,7 +55,8 @@ def _run(cmd: list[str]) -> None:
         sys.stderr.write(r.stderr)
 
 
-def build_hip(force: bool = False, save_temps: bool = False, stamps: bool = False) -> str:
+def build_hip(force: bool = False, save_temps: bool = False, stamps: bool = False, variant: str = "",
+              defines: "list[str] | None" = None) -> str:
     """stamps=True: the diagnostic build (-DVT_STAMPS: in-kernel cycle stamps in the GEMM main loops,
     printed by vt_op_gemm_bench) into libvittrack_hip_stamps.so; never loaded by the product - point
     VITTRACK_HIP_LIB at it from a tuning tool."""
@@ -63,6 +64,9 @@ def build_hip(force: bool = False, save_temps: bool = False, stamps: bool = Fals
     if stamps:
         OBJ = os.path.join(PKG, "build_stamps")
         LIB_HIP = os.path.join(PKG, "libvittrack_hip_stamps.so")
+    if variant:     # tuning builds (python build.py --variant NAME -DMACRO ...): never loaded by the product
+        OBJ = os.path.join(PKG, "build_" + variant)
+        LIB_HIP = os.path.join(PKG, f"libvittrack_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "vt_common.hpp"), os.path.join(CSRC, "k_gemm_util.hpp"),
                os.path.join(PKG, "..", "include", "vittrack_hip.h")]
@@ -72,7 +76,7 @@ def build_hip(force: bool = False, save_temps: bool = False, stamps: bool = Fals
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            flags = list(HIP_FLAGS) + (["-DVT_STAMPS"] if stamps else [])
+            flags = list(HIP_FLAGS) + (["-DVT_STAMPS"] if stamps else []) + list(defines or [])
             if s in FAST_CONTRACT:
                 flags[flags.index("-ffp-contract=off")] = "-ffp-contract=fast"
             cmd = [HIPCC] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
@@ -116,6 +120,10 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     if "--stamps" in sys.argv:
         print(build_hip(force, stamps=True))
+        sys.exit(0)
+    if "--variant" in sys.argv:
+        print(build_hip(force, variant=sys.argv[sys.argv.index("--variant") + 1],
+                        defines=[a for a in sys.argv if a.startswith("-D")]))
         sys.exit(0)
     print(build_hip(force, save_temps="--save-temps" in sys.argv))
     if os.path.exists(os.path.join(HOST, "host_capi.cpp")):

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         __syncthreads();
         float bias8[8];
         if constexpr (EARLY) {
+            vm_drain();
             if constexpr (PIECES == 2)
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_a[0][1]),
                              "+v"(e_a[1][0]), "+v"(e_a[1][1]) : : "memory");
@@ -388,10 +389,10 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             if constexpr (FITS) __syncthreads();
             // folded LayerNorm: y = a_r * acc + (b_r * colsum[n] + bias[n]); without one a_r = 1, b_r = 0
             // and fma(1, acc, bias) = acc + bias exactly
-            if (ln) {
+            // unconditional: under `if (ln)` the waited and the unwaited registers meet in a phi whose copies
+            // hipcc places in front of the wait
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
-            }
+            for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mr = wr * WM + i * 32 + l31;
@@ -456,10 +457,10 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
             // folded LayerNorm: the row terms of the 16 rows per 32-row block this lane's registers hold,
             // fetched once (not per column group); rows past M read the last row, never stored
             float2 vrs[TM][4][4];
-            if (ln) {
+            // unconditional: under `if (ln)` the waited and the unwaited registers meet in a phi whose copies
+            // hipcc places in front of the wait
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
-            }
+            for (int i = 0; i < TM; ++i) ln_wait(lnp[i]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 // lane l31 (both halves) works out the terms of row l31 of the 32-row block, then every lane

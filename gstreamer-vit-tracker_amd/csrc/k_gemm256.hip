@@ -487,13 +487,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 if (m < p.M) {
                     *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
                     *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
-                    if (p.cstat && (c8 & 3) == 0) {
-                        // write-through (sc1) store: the row panel's last workgroup may read it in this
-                        // launch (finalize below); the same bytes either way
-                        const unsigned long long bits = ((unsigned long long)__float_as_uint(cm2) << 32) | __float_as_uint(csum);
-                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.cstat + (size_t)m * nchunk + (n8 / VT_STAT_CHUNK)),
-                                           bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                }
+                // chunk partials: two chunks (this quad's and the next one's, fetched from lane + 4) per 16-B
+                // WRITE-THROUGH (sc1) store - the row panel's last workgroup may read them in this launch
+                // (finalize below). As 8-B sc1 stores they were 518 k single fabric writes per launch (an 8-B
+                // write-through store costs 2.7x a 16-B one per byte): + 5 us on fc2.
+                const float nsum = __shfl_down(csum, 4), nm2 = __shfl_down(cm2, 4);
+                if (m < p.M && p.cstat && (c8 & 7) == 0) {
+                    const f32x4_t v4 = {csum, cm2, nsum, nm2};
+                    float2* dst = p.cstat + (size_t)m * nchunk + (n8 / VT_STAT_CHUNK);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v4) : "memory");
                 }
             }
         };
@@ -521,7 +524,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // place of an acquire (MI355X guide, "Valid forms": one signalling lane per workgroup after every
         // storing wave's vmcnt(0); one 128-KiB-LDS workgroup per CU; 8-B sc1 stores and loads); no dispatch
         // order, timing or placement is assumed. The counter is left at zero for the next launch.
+#ifdef VT_AB_NOFINALIZE      /* tuning builds only: what the in-kernel finalize costs */
+        if (false) {
+#else
         if (p.rowstat_out) {
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int* s_last = reinterpret_cast<int*>(smem);

@@ -71,6 +71,9 @@ __device__ __forceinline__ float quad_sum(float v) {
 // covers (quad-uniform: the four lanes of a quad hold the four 8-column groups of one chunk of one row),
 // and the bf16 pair. Fixed summation order -> run-to-run identical.
 __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, float& m2) {
+#ifdef VT_AB_NOSTATS      /* tuning builds only: what the statistics cost */
+    sum = x[0]; m2 = x[1]; return;
+#endif
     float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     s = quad_sum(s);
     const float mc = s * (1.0f / VT_STAT_CHUNK);
@@ -82,6 +85,10 @@ __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, f
 }
 __device__ __forceinline__ void x_split8(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
     uint32_t h[4], l[4];
+#ifdef VT_AB_NOSPLIT      /* tuning builds only: what the second half of the pair costs */
+    for (int e = 0; e < 4; ++e) { h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]); l[e] = 0; }
+    hi = u32x4_t{h[0], h[1], h[2], h[3]}; lo = u32x4_t{l[0], l[1], l[2], l[3]}; return;
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
@@ -127,7 +134,16 @@ __device__ __forceinline__ void ln_prefetch(const GemmArgs& p, int m, int half, 
     for (int i = 0; i < 8; ++i)
         if (i < nl) part.v[i] = gload_b128_asm(src + i * 16);
 }
+// vm_drain: an operand-free wait in front of every wait that names registers. hipcc may place register
+// copies of a "+v" operand directly in front of its asm statement (it does, for LnPart under control
+// flow); with the drain ahead of them such a copy reads a retired load. tests/test_isa_asm_loads.py checks
+// the emitted ISA for exactly this.
+__device__ __forceinline__ void vm_drain() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);          // the scheduler would hoist those copies over an operand-free asm
+}
 __device__ __forceinline__ void ln_wait(LnPart& a) {
+    vm_drain();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(a.v[4]), "+v"(a.v[5]),
                  "+v"(a.v[6]), "+v"(a.v[7]) : : "memory");
 }

@@ -1849,7 +1849,13 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
     g.M = M; g.N = N; g.K = K; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
     const bool x_epi = epilogue == EPI_F32 || epilogue == EPI_RESID || epilogue == EPI_F32_POS;
-    if (x_epi) { g.Xh = (bf16_t*)dcb.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.cstat = (float2*)dcst.p; }
+    DevBuf dcnt, dro;
+    if (x_epi) {      // as the engine launches it: chunk partials + the row terms finalized by the last workgroup of each panel
+        g.Xh = (bf16_t*)dcb.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.cstat = (float2*)dcst.p;
+        HIPCHK(dcnt.alloc((size_t)((M + 255) / 256 + 1) * 4)); HIPCHK(dro.alloc((size_t)M * 8 + 16));
+        HIPCHK(hipMemset(dcnt.p, 0, (size_t)((M + 255) / 256 + 1) * 4));
+        g.rowstat_out = (float2*)dro.p; g.panel_cnt = (unsigned*)dcnt.p; g.ln_eps = 1e-6f;
+    }
     else if (epilogue == EPI_QKV || epilogue == EPI_GELU_BF16) { g.rowstat = (const float2*)drs.p; g.colsum = (const float*)db.p; }
     g.pos = (const float*)dc.p; g.pos_rows = M;
     g.qk = (bf16_t*)dcb.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
