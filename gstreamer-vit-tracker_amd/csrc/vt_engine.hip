@@ -363,16 +363,22 @@ int Engine::load_blob_device(const void* d_src, size_t bytes) {
     blob_bytes = bytes;
     HIPCHK(hipMalloc((void**)&d_blob, blob_bytes));
     HIPCHK(hipMemcpy(d_blob, d_src, blob_bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));      // a device-to-device hipMemcpy may return early; the engine's
+                                                // stream (non-blocking) is not ordered behind the null stream
     hc.resize(tbl);
     // index_blob only touches [0, tbl) of the host copy
     return index_blob(hc.data(), blob_bytes);
 }
 
+// zero-filled device buffer. The fill is ordered on the ENGINE's stream: that stream is non-blocking, so a
+// hipMemset on the null stream (asynchronous for device memory) is not ordered against the kernels the
+// engine launches next - the LayerNorm fold at construction raced with the fill of its own output when
+// the null stream was busy zeroing the gigabytes of a several-hundred-stream engine.
 template <typename T>
-static hipError_t dalloc0(T** p, size_t count) {
+static hipError_t dalloc0(T** p, size_t count, hipStream_t s) {
     hipError_t e = hipMalloc((void**)p, count * sizeof(T));
     if (e != hipSuccess) return e;
-    return hipMemset(*p, 0, count * sizeof(T));
+    return hipMemsetAsync(*p, 0, count * sizeof(T), s);
 }
 
 // HBM the activations of B streams need (bytes), as alloc_buffers() lays them out
@@ -398,16 +404,16 @@ int Engine::alloc_buffers() {
             return set_err(VT_ERR_OOM, "%d streams need %.1f MiB of HBM for activations; %.1f MiB "
                            "are free on device %d", B, need / 1048576.0, free_b / 1048576.0, device);
     }
-    HIPCHK(dalloc0(&d_patches, M * d.kpad));
-    HIPCHK(dalloc0(&d_xh, M * d.D));
-    HIPCHK(dalloc0(&d_xl, M * d.D));
-    HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK)));
-    HIPCHK(dalloc0(&d_rstat, M + 1));      // + 1: the 4-wave kernel fetches row terms as aligned pairs
-    HIPCHK(dalloc0(&d_panel_cnt, (M + 255) / 256 + 1));
+    HIPCHK(dalloc0(&d_patches, M * d.kpad, stream));
+    HIPCHK(dalloc0(&d_xh, M * d.D, stream));
+    HIPCHK(dalloc0(&d_xl, M * d.D, stream));
+    HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK), stream));
+    HIPCHK(dalloc0(&d_rstat, M + 1, stream));      // + 1: the 4-wave kernel fetches row terms as aligned pairs
+    HIPCHK(dalloc0(&d_panel_cnt, (M + 255) / 256 + 1, stream));
     {   // fold LayerNorm 1 / 2 of every layer into the QKV / fc1 weights
         const size_t rows = (size_t)3 * d.D + d.mlp;
-        HIPCHK(dalloc0(&d_foldw, (size_t)d.L * rows * d.D));
-        HIPCHK(dalloc0(&d_foldv, (size_t)d.L * 2 * rows));
+        HIPCHK(dalloc0(&d_foldw, (size_t)d.L * rows * d.D, stream));
+        HIPCHK(dalloc0(&d_foldv, (size_t)d.L * 2 * rows, stream));
         for (int l = 0; l < d.L; ++l) {
             LayerW& w = layers[l];
             bf16_t* fw = d_foldw + (size_t)l * rows * d.D;
@@ -420,23 +426,23 @@ int Engine::alloc_buffers() {
         }
         HIPCHK(hipStreamSynchronize(stream));
     }
-    HIPCHK(dalloc0(&d_qk, M * 2 * d.D));
-    HIPCHK(dalloc0(&d_vt, (size_t)B * d.H * 64 * d.npad));
-    HIPCHK(dalloc0(&d_attn, M * d.D));
-    HIPCHK(dalloc0(&d_mlp, M * d.mlp));
-    HIPCHK(dalloc0(&d_feat, Ms * d.D));
-    HIPCHK(dalloc0(&d_ta, Ms * d.C));
-    HIPCHK(dalloc0(&d_tb, Ms * d.C));
-    HIPCHK(dalloc0(&d_zeros, (size_t)128));
-    HIPCHK(dalloc0(&d_headout, Ms * 8));
-    HIPCHK(dalloc0(&d_states, (size_t)B));
+    HIPCHK(dalloc0(&d_qk, M * 2 * d.D, stream));
+    HIPCHK(dalloc0(&d_vt, (size_t)B * d.H * 64 * d.npad, stream));
+    HIPCHK(dalloc0(&d_attn, M * d.D, stream));
+    HIPCHK(dalloc0(&d_mlp, M * d.mlp, stream));
+    HIPCHK(dalloc0(&d_feat, Ms * d.D, stream));
+    HIPCHK(dalloc0(&d_ta, Ms * d.C, stream));
+    HIPCHK(dalloc0(&d_tb, Ms * d.C, stream));
+    HIPCHK(dalloc0(&d_zeros, (size_t)128, stream));
+    HIPCHK(dalloc0(&d_headout, Ms * 8, stream));
+    HIPCHK(dalloc0(&d_states, (size_t)B, stream));
     {   // B frame descriptors + the pass's PassOut behind them (one upload per pass)
         void* p = nullptr;
         HIPCHK(hipMalloc(&p, frames_block_bytes()));
-        HIPCHK(hipMemset(p, 0, frames_block_bytes()));
+        HIPCHK(hipMemsetAsync(p, 0, frames_block_bytes(), stream));
         d_frames = (FrameDesc*)p;
     }
-    HIPCHK(dalloc0(&d_results, (size_t)B));
+    HIPCHK(dalloc0(&d_results, (size_t)B, stream));
     HIPCHK(hipHostMalloc((void**)&h_frames, frames_block_bytes() * RING));
     HIPCHK(hipHostMalloc((void**)&h_results, sizeof(vt_result) * B));
     HIPCHK(hipHostMalloc((void**)&h_state, sizeof(StreamState)));
@@ -446,6 +452,7 @@ int Engine::alloc_buffers() {
     for (int i = 0; i < RING; ++i) HIPCHK(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
     h_initialized.assign(B, 0);
     known.assign((size_t)B, StreamState{});
+    HIPCHK(hipStreamSynchronize(stream));       // every fill has landed before the handle is handed out
     return VT_OK;
 }
 
@@ -1077,7 +1084,7 @@ int vt_group_enable_taps(vt_group* g, int enable) try {
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (enable && !e->d_taps)      // per slot: the hi and the lo half of the residual stream
-        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * 2 * e->B * e->d.ntok * e->d.D));
+        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * 2 * e->B * e->d.ntok * e->d.D, e->stream));
     e->taps = enable != 0;
     return VT_OK;
 } VT_NOTHROW_INT
