@@ -419,8 +419,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         for (int mf = 0; mf < 4; ++mf) acc[i][mf][j][nf] = b4;
                 }
         }
+#ifdef VT_STAMPS
+        const unsigned long long xs_t0 = __builtin_amdgcn_s_memtime(), xs_r0 = __builtin_amdgcn_s_memrealtime();
+        (void)xs_r0;
+#endif
         if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
         else g256_mainloop<true>(p, smem, m0, n0, acc);
+#ifdef VT_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long xs_t1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics (vt_common.hpp) ----------
         // Two passes (i = 0, 1) of 128 rows x 256 f32 staged in LDS: row lr = wr*64 + mf*16 + l15 of the
         // pass, 16-B chunk ch of the row stored at ch ^ (lr & 7). Written out row-wise, 8 consecutive
@@ -513,6 +522,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         stage_pass(1);
         __syncthreads();
         write_pass(1, ad1);
+#ifdef VT_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long xs_t2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- row terms of the LayerNorm that follows, by the LAST workgroup of the row panel ------------
         // (instead of a launch of their own: 24 per pass, 6.5 us each between 40-90 us GEMMs.) The N / 256
         // workgroups of a 256-row panel each stored their chunk partials write-through; every wave drains
@@ -579,6 +593,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 if (hpart == 0 && m < p.M) p.rowstat_out[m] = make_float2(rstd, -mean * rstd);
             }
         }
+#ifdef VT_STAMPS     // phases of an X-epilogue launch, per wave: [main loop, epilogue, stats hand-off, total]
+        if (p.dbg && lane == 0) {
+            const unsigned long long xs_t3 = __builtin_amdgcn_s_memtime();
+            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+            d[0] = xs_t1 - xs_t0; d[1] = xs_t2 - xs_t1; d[2] = xs_t3 - xs_t2; d[3] = xs_t3 - xs_t0;
+#ifdef VT_STAMPS_CLOCK   // shader clock during the launch: s_memtime ticks per 100-MHz s_memrealtime tick
+            d[0] = __builtin_amdgcn_s_memrealtime() - xs_r0;
+#endif
+        }
+#endif
     } else {
         bool v_tile = false;
         float scale = 1.0f;
@@ -829,7 +853,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     bool after16 = false;
 #ifdef VT_STAMPS
     unsigned long long sp_wait = 0, sp_main = 0, sp_epi = 0, sp_a, sp_b;
-    const unsigned long long sp_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long sp_t0 = __builtin_amdgcn_s_memtime(), sp_r0 = __builtin_amdgcn_s_memrealtime();
+    (void)sp_r0;
 #define G256P_T(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define G256P_T(v)
@@ -1175,6 +1200,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         d[0] = sp_wait; d[1] = sp_epi; d[2] = sp_main; d[3] = __builtin_amdgcn_s_memtime() - sp_t0;
+#ifdef VT_STAMPS_CLOCK
+        d[0] = __builtin_amdgcn_s_memrealtime() - sp_r0;
+#endif
     }
 #endif
 #undef G256P_BODY
