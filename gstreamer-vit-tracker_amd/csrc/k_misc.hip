@@ -345,19 +345,18 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
         }
         __syncthreads();
     }
-    if (tid != 0) return;
-    StreamState& s = a.states[b];
+    // the 3x3 window around the argmax: its nine cells are evaluated by nine lanes at once (the loads and
+    // the five sigmoids of a cell are independent of the other cells - done one after the other by one
+    // lane they were nine dependent round trips at the end of every pass), then lane 0 adds the terms in
+    // vto_decode's order (dy, dx ascending), so the sums are bit-identical to the serial form
+    __shared__ float s_win[9][5];      // w, w*cx, w*cy, w*sig(o3), w*sig(o4); w < 0: cell outside the map
     const int idx = s_idx[0];
-    const float score = sigmoidf_(s_logit[idx & 255][0]);  // cell i is handled by thread i % 256
     const int grid = a.grid;
     const int bx = idx % grid, by = idx / grid;
-    // response^2-weighted mean over the 3x3 window around the argmax (see vto_decode); head_out was
-    // written by the preceding head_out_kernel launch.
-    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int ix = bx + dx, iy = by + dy;
-            if (ix < 0 || iy < 0 || ix >= grid || iy >= grid) continue;
+    if (tid < 9) {
+        const int ix = bx + tid % 3 - 1, iy = by + tid / 3 - 1;
+        float t[5] = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (ix >= 0 && iy >= 0 && ix < grid && iy < grid) {
             const float* o = a.head_out + ((size_t)b * ns + iy * grid + ix) * 8;
             const float r = sigmoidf_(o[0]) * a.hann[iy * grid + ix];
             const float w = r * r;
@@ -365,12 +364,26 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             const float offy = 3.0f * sigmoidf_(o[2]) - 1.0f;
             const float cxj = ((float)ix + offx) / (float)grid;
             const float cyj = ((float)iy + offy) / (float)grid;
-            sw = sw + w;
-            scx = scx + w * cxj;
-            scy = scy + w * cyj;
-            sbw = sbw + w * sigmoidf_(o[3]);
-            sbh = sbh + w * sigmoidf_(o[4]);
+            t[0] = w; t[1] = w * cxj; t[2] = w * cyj; t[3] = w * sigmoidf_(o[3]); t[4] = w * sigmoidf_(o[4]);
         }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_win[tid][k] = t[k];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    StreamState& s = a.states[b];
+    const float score = sigmoidf_(s_logit[idx & 255][0]);  // cell i is handled by thread i % 256
+    // response^2-weighted mean over the window (see vto_decode); head_out was written by the preceding
+    // head_out_kernel launch.
+    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
+    for (int j = 0; j < 9; ++j) {
+        if (s_win[j][0] < 0.0f) continue;
+        sw = sw + s_win[j][0];
+        scx = scx + s_win[j][1];
+        scy = scy + s_win[j][2];
+        sbw = sbw + s_win[j][3];
+        sbh = sbh + s_win[j][4];
+    }
     const float cxn = scx / sw, cyn = scy / sw, wn = sbw / sw, hn = sbh / sw;
     const float side = s.geo[3];
     const float cx = (s.geo[0] + 0.5f) + cxn * side;
