@@ -499,7 +499,11 @@ void vto_draw_cursor_rgb(uint8_t* d, size_t w, size_t h, int32_t cx, int32_t cy)
     }
 }
 
-/* src/drawing_rgb.rs:86-104; unknown characters: get_glyph returns Err (src/drawing.rs:99) -> skipped */
+/* src/drawing_rgb.rs:86-104. DELIBERATE DEVIATION for characters outside the font: the reference's get_glyph
+ * panics ("No char!", src/drawing.rs:96-100, and the host is built with panic = "abort"), so its `if let Ok`
+ * at drawing_rgb.rs:89 never sees an Err; a library must not abort its host, so unknown characters are
+ * skipped here and in the HIP overlay kernel (the pen still advances), which is what that `if let` would do
+ * if get_glyph returned the error its signature promises. */
 void vto_draw_text_rgb(uint8_t* d, size_t w, size_t h, const char* text, int32_t x, int32_t y,
                        int32_t scale, uint8_t luma) {
     size_t len = w * h * 3;

@@ -18,3 +18,16 @@ python3 bench.py --workload cfg2 --no-cpu-baseline --no-host-leg --no-single-leg
 python3 bench.py --workload cfg5 --steps 100 --no-cpu-baseline --no-host-leg --no-single-leg > $O/bench_cfg5.json 2>> $O/bench.err
 echo "benches done"
 find $O -name "*kernel_stats.csv" | head
+# parity report (prints of the closed-loop, teacher-forced and stage-tap tests), single stream, in-kernel stamps
+python3 -m pytest tests/test_gpu_trajectories.py tests/test_gpu_pipeline.py -q -s -k "traject or closed_loop or teacher or taps or large_engine" > $O/r03_parity_report.txt 2>&1
+echo "parity report done"
+python3 bench.py --streams 1 --groups 1 --no-cpu-baseline --no-host-leg > $O/bench_cfg3_single_stream.json 2>> $O/bench.err
+export VITTRACK_HIP_LIB=$PWD/gstreamer-vit-tracker_amd/libvittrack_hip_clk.so
+{ echo "# build.py --variant clk -DVT_STAMPS -DVT_STAMPS_CLOCK; per wave: [s_memrealtime ticks (100 MHz), epilogue | hand-off, main loop | epilogue, total] s_memtime cycles";
+  for a in "21600 3072 768 2 19" "21600 2304 768 4 19" "21600 768 3072 1 18" "21600 768 768 1 18"; do echo "one_gemm $a 20:"; python3 tools/one_gemm.py $a 20 2>&1 | grep -v amdgpu; done; } > $O/r03_gemm_clock_stamps.txt
+export VITTRACK_HIP_LIB=$PWD/gstreamer-vit-tracker_amd/libvittrack_hip_stamps.so
+{ echo "# build.py --stamps; persistent kernel: [top-of-tile wait, epilogue, main loop, total]; X-epilogue kernel: [main loop, epilogue, statistics hand-off, total]; cycles per wave";
+  for a in "21600 3072 768 2 19" "21600 2304 768 4 19" "21600 768 3072 1 18" "21600 768 768 1 18" "21600 3072 768 2 16"; do echo "one_gemm $a 20:"; python3 tools/one_gemm.py $a 20 2>&1 | grep -v amdgpu; done; } > $O/r03_gemm_phase_stamps.txt
+unset VITTRACK_HIP_LIB
+hipcc --offload-arch=gfx950 -O3 -w tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $O/r03_mfma_peak.txt 2>&1
+echo "stamps done"
