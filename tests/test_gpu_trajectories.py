@@ -152,6 +152,47 @@ def test_closed_loop_through_the_batched_large_tile_path(gpu, name, capsys):
     assert dscore.max() < 0.10
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_teacher_forced_on_the_trajectory_fixtures(gpu, name, capsys):
+    """open loop on the three shipped heads: before every frame the HIP state is overwritten with the
+    oracle's state of that frame (the fixture's `state`), so each of the 300 frames is ONE forward pass on
+    the oracle's own input - closed-loop runs can differ in the argmax cell merely because their crops
+    differ by a pixel (cfg5: 2 frames); on identical inputs the cell must be the oracle's wherever its
+    top-1/top-2 margin is >= MARGIN_EPS, the box within +-1 px, the score within 0.03 on the same cell"""
+    fx = _fixture(name)
+    cfg = str(fx["config"])
+    weights = gpu.weights.ensure_weights(cfg)
+    assert _sha256(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
+    sc = _clip(gpu, fx)
+    w, h, n = sc.w, sc.h, int(fx["frames"])
+    trk = gpu.VitTrack(weights)
+    g = trk.as_group()
+    idx, boxes, scores = [], [], []
+    for t in range(n):
+        f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+        if t == 0:
+            trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
+        g.set_state_box(0, fx["state"][t])
+        r = trk.update(f)
+        idx.append(g.read_state()["last_idx"])
+        boxes.append(r.bbox)
+        scores.append(r.score)
+    idx, boxes, scores = np.array(idx), np.array(boxes), np.array(scores)
+    d = np.abs(boxes - fx["bbox"])
+    clear = fx["margin"] >= MARGIN_EPS
+    differ = idx != fx["idx"]
+    ds = np.abs(scores - fx["score"])
+    with capsys.disabled():
+        print(f"\n[teacher-forced, {name}] {n} frames: frames with oracle margin < {MARGIN_EPS}: {(~clear).sum()}; argmax "
+              f"differs on {differ.sum()} frames (largest oracle margin among them "
+              f"{fx['margin'][differ].max() if differ.any() else 0:.5f}); max |delta box| {d.max()} px, identical boxes "
+              f"{(d.max(axis=1) == 0).sum()}; max |delta score| {ds.max():.4f}")
+    assert not (differ & clear).any(), \
+        f"argmax differs at margin {fx['margin'][differ & clear].max():.4f} (frame {int(np.argmax(differ & clear))})"
+    assert d.max() <= 1, f"open-loop box differs by {d.max()} px at frame {int(d.max(axis=1).argmax())}"
+    assert ds[~differ].max() < 0.03 and ds.max() < 0.10
+
+
 def test_teacher_forced_on_the_noisy_first_generation_head(gpu, capsys):
     fx = _fixture("forced_cfg3_300.npz")
     with np.load(os.path.join(GOLD, "head_gen1_cfg3.npz")) as z:
