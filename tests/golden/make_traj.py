@@ -7,6 +7,8 @@ from /root/reference (it holds no vectors for this path, SURVEY.md §8c: PARITY 
   python tests/golden/make_traj.py traj cfg3 --frames 300 --seed 1
       closed loop of the oracle on the synthetic clip -> tests/golden/traj_<cfg>_<frames>.npz
       (per frame: box, score, success, argmax cell, top-1/top-2 response margin, state box)
+  python tests/golden/make_traj.py traj cfg3 --frames 300 --seed 9 --square 80 --tag _b
+      a second clip (other background, phase and target size) -> traj_cfg3_300_b.npz
   python tests/golden/make_traj.py gen1head cfg3
       the FIRST-GENERATION head: fitted on ~128 CPU-oracle samples only (noisy, 1-2 px
       of frame-to-frame jitter) -> tests/golden/head_gen1_<cfg>.npz
@@ -62,8 +64,9 @@ def gen1_weights(cfg: str) -> str:
     return vt.weights.ensure_weights(cfg, path=path, head=head)
 
 
-def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True):
+def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, square: int = 0):
     w, h, sq = CLIPS[cfg]
+    sq = square or sq
     sc = vt.synth.MovingSquare(w, h, sq, seed=seed)
     trk = R.VitTrackRef(weights)
     hann = trk.m.t["hann"].reshape(-1)
@@ -103,10 +106,12 @@ if __name__ == "__main__":
     ap.add_argument("cfg", choices=sorted(CLIPS))
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--square", type=int, default=0, help="target side in px (default: the configuration's clip)")
+    ap.add_argument("--tag", default="", help="suffix of the output file, e.g. _b for a second clip")
     a = ap.parse_args()
     if a.what == "traj":
         run(a.cfg, vt.weights.ensure_weights(a.cfg), a.frames, a.seed,
-            os.path.join(HERE, f"traj_{a.cfg}_{a.frames}.npz"))
+            os.path.join(HERE, f"traj_{a.cfg}_{a.frames}{a.tag}.npz"), square=a.square)
     elif a.what == "gen1head":
         import importlib.util
         spec = importlib.util.spec_from_file_location("fit_head", os.path.join(HERE, "fit_head.py"))

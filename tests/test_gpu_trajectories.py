@@ -56,10 +56,15 @@ def _clip(gpu, fx):
 # stage (tools/arbiter.py, profiles/r03_arbiter_cfg5.txt: residual stream 2.2e-3 both, decoded float box
 # 0.03 px both) - bf16 noise, not a kernel; what turned it into 2 px in closed loop was the head's
 # conditioning on 160-px targets, so the cfg5 head was refitted on targets of that size with feature noise.)
+# The `_b` fixtures are second clips: other background noise, path phase and target size (cfg3 80 px, cfg2 48 px,
+# cfg5 128 px; seed 9) - the heads were fitted on a range of sizes, the first clips use one each.
 BARS = {"traj_cfg3_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg2_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
-        "traj_cfg5_300.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
-FIXTURES = ["traj_cfg3_300.npz", "traj_cfg2_300.npz", "traj_cfg5_300.npz"]
+        "traj_cfg5_300.npz": dict(px=1, min_iou=0.95, mean_iou=0.99),
+        "traj_cfg3_300_b.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
+        "traj_cfg2_300_b.npz": dict(px=1, min_iou=0.88, mean_iou=0.99),
+        "traj_cfg5_300_b.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
+FIXTURES = [n for n in BARS if not n.endswith("_b.npz") or os.path.exists(os.path.join(GOLD, n))]   # first clips: required
 
 
 @pytest.mark.parametrize("name", FIXTURES)
