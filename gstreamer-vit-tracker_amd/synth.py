@@ -13,9 +13,12 @@ import numpy as np
 
 class MovingSquare:
     def __init__(self, width=1920, height=1080, square=64, seed=0, period=300, amp=None,
-                 path="lissajous", center=None):
+                 path="lissajous", center=None, hide=None):
+        """hide = (t0, t1): the target is absent from frames t0 <= t < t1 (occlusion; gt_box still
+        reports where it would be)"""
         self.w, self.h, self.sq, self.seed, self.period, self.path = width, height, square, seed, \
             period, path
+        self.hide = tuple(hide) if hide is not None else None
         rng = np.random.default_rng(seed)
         self.bg_y = rng.integers(44, 77, size=(height, width), dtype=np.uint8)
         self.sq_y = (200 + rng.integers(-12, 13, size=(square, square))).astype(np.uint8)
@@ -46,10 +49,11 @@ class MovingSquare:
         """-> (Y [h,w], UV [ceil(h/2), w]) uint8"""
         x, y, s, _ = self.gt_box(t)
         yy = self.bg_y.copy()
-        yy[y:y + s, x:x + s] = self.sq_y
         uv = np.full(((self.h + 1) // 2, (self.w + 1) // 2, 2), 128, np.uint8)
-        uv[y // 2:(y + s + 1) // 2, x // 2:(x + s + 1) // 2, 0] = self.sq_u
-        uv[y // 2:(y + s + 1) // 2, x // 2:(x + s + 1) // 2, 1] = self.sq_v
+        if self.hide is None or not (self.hide[0] <= t < self.hide[1]):
+            yy[y:y + s, x:x + s] = self.sq_y
+            uv[y // 2:(y + s + 1) // 2, x // 2:(x + s + 1) // 2, 0] = self.sq_u
+            uv[y // 2:(y + s + 1) // 2, x // 2:(x + s + 1) // 2, 1] = self.sq_v
         uv = uv.reshape(uv.shape[0], -1)[:, : self.w + (self.w & 1)]
         return yy, uv
 

@@ -64,10 +64,10 @@ def gen1_weights(cfg: str) -> str:
     return vt.weights.ensure_weights(cfg, path=path, head=head)
 
 
-def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, square: int = 0):
+def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, square: int = 0, hide=None):
     w, h, sq = CLIPS[cfg]
     sq = square or sq
-    sc = vt.synth.MovingSquare(w, h, sq, seed=seed)
+    sc = vt.synth.MovingSquare(w, h, sq, seed=seed, hide=hide)
     trk = R.VitTrackRef(weights)
     hann = trk.m.t["hann"].reshape(-1)
     rec = {k: [] for k in ("state", "bbox", "score", "success", "idx", "idx2", "margin", "gt")}
@@ -92,7 +92,7 @@ def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, 
                   f"({time.time() - t0:.0f}s)", flush=True)
     np.savez_compressed(
         out, config=cfg, frame_w=w, frame_h=h, square=sq, seed=seed, frames=frames,
-        weights_sha256=sha256_file(weights),
+        weights_sha256=sha256_file(weights), hide=np.array(hide if hide else (0, 0), np.int32),
         state=np.array(rec["state"], np.float32), bbox=np.array(rec["bbox"], np.int32),
         score=np.array(rec["score"], np.float32), success=np.array(rec["success"], np.int8),
         idx=np.array(rec["idx"], np.int32), idx2=np.array(rec["idx2"], np.int32),
@@ -108,10 +108,12 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--square", type=int, default=0, help="target side in px (default: the configuration's clip)")
     ap.add_argument("--tag", default="", help="suffix of the output file, e.g. _b for a second clip")
+    ap.add_argument("--hide", type=int, nargs=2, default=None, metavar=("T0", "T1"),
+                    help="occlusion: the target is absent from frames T0 <= t < T1")
     a = ap.parse_args()
     if a.what == "traj":
         run(a.cfg, vt.weights.ensure_weights(a.cfg), a.frames, a.seed,
-            os.path.join(HERE, f"traj_{a.cfg}_{a.frames}{a.tag}.npz"), square=a.square)
+            os.path.join(HERE, f"traj_{a.cfg}_{a.frames}{a.tag}.npz"), square=a.square, hide=a.hide)
     elif a.what == "gen1head":
         import importlib.util
         spec = importlib.util.spec_from_file_location("fit_head", os.path.join(HERE, "fit_head.py"))
