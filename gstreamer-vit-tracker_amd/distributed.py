@@ -32,6 +32,37 @@ def broadcast_weights(blob_path: str | None, device="cuda", src: int = 0) -> tor
     return buf
 
 
+def timed_broadcast_weights(blob_path: str | None, device="cuda", src: int = 0):
+    """broadcast_weights plus the record bench.py prints under `collective`: which backend moved the
+    bytes, how many ranks the process group really has (dist.get_world_size(), not an argument), the
+    message size and the wall time of the two broadcasts on this rank (device work synchronised)."""
+    import time
+    is_cuda = str(device).startswith("cuda")
+    if is_cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    buf = broadcast_weights(blob_path, device=device, src=src)
+    if is_cuda:
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+           "broadcast_bytes": int(buf.numel()), "broadcast_ms": aggregate_max_time(ms, device=device),
+           "collectives_per_frame": 0}
+    return buf, rec
+
+
+def gather_per_rank(local_value: float, device="cpu") -> list:
+    """[value of rank 0, value of rank 1, ...] on every rank (one all_gather, outside the timed region);
+    without a process group the one local value."""
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([float(local_value)], dtype=torch.float64, device=device)
+        parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        return [float(p.item()) for p in parts]
+    return [float(local_value)]
+
+
 def shard_streams(n_streams: int, rank: int, world: int) -> list[int]:
     """Global stream ids owned by `rank` (round-robin; no data moves between ranks)."""
     return list(range(rank, n_streams, world))
@@ -53,7 +84,10 @@ def plan_rank(rank: int, world: int, streams_per_gpu: int, ring: int) -> dict:
     rank's data: ranks exchange only the start-up weight blob and, at the end, their wall times."""
     if not (0 <= rank < world) or streams_per_gpu < 1 or ring < 1:
         raise ValueError("bad rank / world / streams / ring")
-    return {"clip_seed": rank, "phase": [(i * ring) // streams_per_gpu for i in range(streams_per_gpu)],
+    # consecutive clip positions: the frames one engine needs at a step are then ONE contiguous range of
+    # the host's frame ring (two at its wrap), which is what lets the full-frame upload leg move an
+    # engine's frames with one copy; distinct positions while streams_per_gpu <= ring
+    return {"clip_seed": rank, "phase": [i % ring for i in range(streams_per_gpu)],
             "global_stream_ids": [rank * streams_per_gpu + i for i in range(streams_per_gpu)]}
 
 

@@ -71,6 +71,27 @@ class TorchModel:
         return out
 
     @torch.no_grad()
+    def forward_head_only(self, patches_bits: np.ndarray) -> np.ndarray:
+        """The same network without the per-stage copies: [ns, 8] head logits only (what the timed
+        float32 CPU baseline of oracle/cpu_fp32.py evaluates per update)."""
+        t, D, H = self.t, self.D, self.H
+        a = torch.from_numpy(bf16_bits_to_f32(patches_bits).copy()).to(self.dtype)
+        x = F.linear(a, t["patch_w"], t["patch_b"].reshape(-1)) + t["pos"]
+        n = x.shape[0]
+        for l in range(self.L):
+            p = f"l{l}."
+            h1 = F.layer_norm(x, (D,), t[p + "ln1_g"].reshape(-1), t[p + "ln1_b"].reshape(-1), self.eps)
+            qkv = F.linear(h1, t[p + "qkv_w"], t[p + "qkv_b"].reshape(-1))
+            q, k, v = (z.reshape(n, H, 64).transpose(0, 1) for z in qkv.split(D, dim=1))
+            o = F.scaled_dot_product_attention(q, k, v).transpose(0, 1).reshape(n, D)
+            x = x + F.linear(o, t[p + "proj_w"], t[p + "proj_b"].reshape(-1))
+            h2 = F.layer_norm(x, (D,), t[p + "ln2_g"].reshape(-1), t[p + "ln2_b"].reshape(-1), self.eps)
+            u = F.gelu(F.linear(h2, t[p + "fc1_w"], t[p + "fc1_b"].reshape(-1)))
+            x = x + F.linear(u, t[p + "fc2_w"], t[p + "fc2_b"].reshape(-1))
+        feat = F.layer_norm(x[self.nt:], (D,), t["norm_g"].reshape(-1), t["norm_b"].reshape(-1), self.eps)
+        return self.head(feat).numpy().astype(np.float32)
+
+    @torch.no_grad()
     def head(self, feat: torch.Tensor) -> torch.Tensor:
         """feat [ns, D] -> [ns, 8] logits: 1x1 conv, three 3x3 convs (zero padding 1) with ReLU, then
         the 1x1 output layer; the blob stores a 3x3 kernel as [C_out][(ky*3+kx)*C_in + c]"""

@@ -24,7 +24,9 @@ def _worker(rank, world, port, blob_path, q):
         agg = vd.aggregate_max_time(0.5 + rank)
         plan = vd.plan_rank(rank, world, 6, 64)
         thr = vd.aggregate_throughput(6 * 10, 0.5 + rank)       # bench.py's own aggregation
-        q.put((rank, digest, t.numel(), shard, agg, plan, thr))
+        per_rank = vd.gather_per_rank(100.0 + rank)
+        _, rec = vd.timed_broadcast_weights(blob_path if rank == 0 else None, device="cpu")
+        q.put((rank, digest, t.numel(), shard, agg, plan, thr, per_rank, rec))
     finally:
         dist.destroy_process_group()
 
@@ -52,12 +54,58 @@ def test_weight_broadcast_and_stream_sharding_gloo(vt, weights_tiny):
     assert got[0][4] == got[1][4] == pytest.approx(1.5)
     # bench.py's per-rank plan: own clip per rank, disjoint global stream ids, same phases
     p0, p1 = got[0][5], got[1][5]
-    assert p0["clip_seed"] != p1["clip_seed"] and p0["phase"] == p1["phase"] == [0, 10, 21, 32, 42, 53]
+    assert p0["clip_seed"] != p1["clip_seed"] and p0["phase"] == p1["phase"] == [0, 1, 2, 3, 4, 5]
     assert sorted(p0["global_stream_ids"] + p1["global_stream_ids"]) == list(range(12))
     # whole-job throughput = frames of all ranks / slowest rank's time, identical on every rank
     for g in got:
         assert g[6]["frames"] == 120 and g[6]["seconds"] == pytest.approx(1.5)
         assert g[6]["frames_per_s"] == pytest.approx(80.0)
+        # per-rank rates in rank order on every rank; the collective record proves the group's size
+        assert g[7] == [100.0, 101.0]
+        assert g[8]["backend"] == "gloo" and g[8]["world_size"] == 2 and g[8]["collectives_per_frame"] == 0
+        assert g[8]["broadcast_bytes"] == os.path.getsize(weights_tiny) and g[8]["broadcast_ms"] > 0
+    assert got[0][8]["broadcast_ms"] == got[1][8]["broadcast_ms"]      # max over ranks, same on both
+
+
+def test_bench_self_launches_its_ranks_gloo_dry_run(vt, weights_tiny):
+    """`python bench.py --gpus 2` with no RANK in the environment starts its two ranks itself
+    (torch.distributed.run as a child; the parent imports neither torch nor HIP), relays rank 0's
+    one JSON line and returns the children's status. --dry-run keeps the ranks on the CPU (gloo):
+    launcher, collective record, per-rank plan and aggregation are what is exercised."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--workload", "tiny", "--streams", "3", "--dry-run"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak"
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["broadcast_bytes"] == os.path.getsize(weights_tiny)
+    # rank r "took" 0.5 + r/4 s for 3 streams x 10 steps: whole job = 60 frames / 0.75 s
+    assert d["per_rank_fps"] == pytest.approx([60.0, 40.0]) and d["value"] == pytest.approx(80.0)
+    assert d["global_stream_ids_rank0"] == [0, 1, 2]
+
+
+def test_bench_launcher_does_not_touch_torch_in_the_parent_and_propagates_failure(vt):
+    """the parent of a self-launch must not initialise the GPU (a HIP-initialised process may not be
+    replaced or forked on this pool): bench.self_launch imports nothing heavy; a failing child
+    (ranks that see fewer devices than --gpus) makes the parent exit non-zero with the reason on stderr"""
+    import subprocess
+    code = ("import sys; sys.argv=['bench.py']; import bench; "
+            "assert 'torch' not in sys.modules and 'gstreamer_vit_tracker_amd' not in sys.modules; print('clean')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
+    if vt.device_count() >= 2:
+        pytest.skip("two GPUs present: the 'needs 2 devices' refusal cannot be provoked")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stderr, r.stderr[-3000:]
 
 
 def test_shard_streams_properties(vt):
