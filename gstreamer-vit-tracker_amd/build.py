@@ -108,7 +108,7 @@ def build_c_client(force: bool = False) -> str:
     src, out = os.path.join(HOST, "c_client.c"), os.path.join(HOST, "c_client")
     if force or _newer(out, [src, os.path.join(PKG, "..", "include", "vittrack_hip.h")]):
         _run(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1",
-              "-o", out, src, "-ldl"])
+              "-pthread", "-o", out, src, "-ldl"])
     return out
 
 

@@ -8,8 +8,15 @@
  *   c_client sizes                                   print the struct sizes the header gives a C compiler
  *   c_client run <lib.so> <weights.vtw> <clip.nv12> <w> <h> <frames> <x> <y> <bw> <bh>
  *       prints one line per update: "t success score x y w h"
+ *   c_client threads <same arguments>
+ *       the threading row of the boundary: the reference constructs the tracker
+ *       on the main thread (src/main.rs:49 -> src/pipeline_ir.rs:89) and calls it only from the GStreamer
+ *       streaming thread (src/pipeline.rs:55-67,110-119). Two trackers are created on the main thread and
+ *       each is driven (init + updates) by a pthread of its own, both at once; prints "k t success score
+ *       x y w h" for tracker k = 0, 1 - every line must equal the single-threaded `run` output.
  */
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +30,29 @@ typedef void (*fn_destroy)(vt_tracker*);
 typedef const char* (*fn_last_error)(void);
 typedef int (*fn_abi)(void);
 typedef void (*fn_cfg_default)(vt_config*);
+
+typedef struct worker {
+    vt_tracker* trk;
+    fn_init_nv12 init_nv12;
+    fn_update_nv12 update_nv12;
+    fn_last_error last_error;
+    const uint8_t* buf;
+    size_t fbytes;
+    int w, h, frames, uvs, rc;
+    vt_bbox box;
+    vt_result* res;      /* [frames] */
+} worker;
+
+static void* worker_main(void* p) {
+    worker* k = (worker*)p;
+    k->rc = k->init_nv12(k->trk, k->buf, k->buf + (size_t)k->w * k->h, k->w, k->h, k->w, k->uvs, k->box);
+    for (int t = 0; t < k->frames && k->rc == VT_OK; ++t) {
+        const uint8_t* y = k->buf + (size_t)t * k->fbytes;
+        k->rc = k->update_nv12(k->trk, y, y + (size_t)k->w * k->h, k->w, k->h, k->w, k->uvs, &k->res[t]);
+    }
+    if (k->rc != VT_OK) fprintf(stderr, "worker: %d %s\n", k->rc, k->last_error());
+    return NULL;
+}
 
 static void* must_sym(void* lib, const char* name) {
     void* p = dlsym(lib, name);
@@ -40,10 +70,11 @@ int main(int argc, char** argv) {
                VT_ABI_VERSION, VT_MAX_STREAMS);
         return 0;
     }
-    if (argc != 12 || strcmp(argv[1], "run") != 0) {
-        fprintf(stderr, "usage: %s sizes | run <lib> <weights> <clip.nv12> <w> <h> <frames> <x> <y> <bw> <bh>\n", argv[0]);
+    if (argc != 12 || (strcmp(argv[1], "run") != 0 && strcmp(argv[1], "threads") != 0)) {
+        fprintf(stderr, "usage: %s sizes | run|threads <lib> <weights> <clip.nv12> <w> <h> <frames> <x> <y> <bw> <bh>\n", argv[0]);
         return 2;
     }
+    const int threaded = strcmp(argv[1], "threads") == 0;
     const char *libp = argv[2], *weights = argv[3], *clip = argv[4];
     const int w = atoi(argv[5]), h = atoi(argv[6]), frames = atoi(argv[7]);
     vt_bbox box;
@@ -94,6 +125,42 @@ int main(int argc, char** argv) {
         return 1;
     }
     const int uvs = (w + 1) / 2 * 2;
+    if (threaded) {
+        vt_tracker* trk2 = NULL;
+        rc = create(weights, 0, &cfg, &trk2);                      /* both constructed on the main thread */
+        if (rc != VT_OK) {
+            fprintf(stderr, "vt_create (2): %d %s\n", rc, last_error());
+            return 1;
+        }
+        worker wk[2];
+        pthread_t th[2];
+        for (int k = 0; k < 2; ++k) {
+            wk[k].trk = k ? trk2 : trk;
+            wk[k].init_nv12 = init_nv12; wk[k].update_nv12 = update_nv12; wk[k].last_error = last_error;
+            wk[k].buf = buf; wk[k].fbytes = fbytes; wk[k].w = w; wk[k].h = h; wk[k].frames = frames;
+            wk[k].uvs = uvs; wk[k].rc = 0; wk[k].box = box;
+            wk[k].res = (vt_result*)calloc((size_t)frames, sizeof(vt_result));
+            if (!wk[k].res || pthread_create(&th[k], NULL, worker_main, &wk[k]) != 0) {
+                fprintf(stderr, "cannot start worker %d\n", k);
+                return 1;
+            }
+        }
+        for (int k = 0; k < 2; ++k) pthread_join(th[k], NULL);
+        for (int k = 0; k < 2; ++k) {
+            if (wk[k].rc != VT_OK) return 1;
+            for (int t = 0; t < frames; ++t) {
+                const vt_result* r = &wk[k].res[t];
+                printf("%d %d %d %.9g %d %d %d %d\n", k, t, r->success, r->score, r->bbox.x, r->bbox.y, r->bbox.width,
+                       r->bbox.height);
+            }
+            free(wk[k].res);
+        }
+        destroy(trk);                                              /* and destroyed on the main thread */
+        destroy(trk2);
+        free(buf);
+        dlclose(lib);
+        return 0;
+    }
     rc = init_nv12(trk, buf, buf + (size_t)w * h, w, h, w, uvs, box);   /* tracker.init(frame 0, bbox) */
     if (rc != VT_OK) {
         fprintf(stderr, "vt_init_nv12: %d %s\n", rc, last_error());
