@@ -17,6 +17,12 @@ from /root/reference (it holds no vectors for this path, SURVEY.md §8c: PARITY 
       update is recorded so that the HIP path can be teacher-forced (vt_group_set_state_box) and
       compared frame by frame, open loop -> tests/golden/forced_<cfg>_<frames>.npz
 
+  python tests/golden/make_traj.py fbox traj_cfg3_300.npz
+      adds `fbox` - the oracle's FLOAT box of every update (x, y, w, h before the integer rounding) - to
+      an existing fixture: every frame is re-evaluated from the fixture's own `state` (one forward pass
+      each, the oracle is deterministic), the stored integer box / score / cell must come out identical,
+      and the float box is appended. The teacher-forced GPU tests assert |HIP float box - fbox| on it.
+
 Each file records the SHA-256 of the weight blob it was made with; the tests rebuild the blob and
 refuse to compare against a fixture made from other weights.
 """
@@ -70,7 +76,7 @@ def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, 
     sc = vt.synth.MovingSquare(w, h, sq, seed=seed, hide=hide)
     trk = R.VitTrackRef(weights)
     hann = trk.m.t["hann"].reshape(-1)
-    rec = {k: [] for k in ("state", "bbox", "score", "success", "idx", "idx2", "margin", "gt")}
+    rec = {k: [] for k in ("state", "bbox", "score", "success", "idx", "idx2", "margin", "gt", "fbox")}
     t0 = time.time()
     for t in range(frames):
         fr = R.Frame.nv12(sc.frame_nv12(t), w, h)
@@ -81,6 +87,7 @@ def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, 
         resp = (1.0 / (1.0 + np.exp(-trk.last["head_out"][:, 0].astype(np.float64)))) * hann
         order = np.argsort(-resp, kind="stable")
         rec["bbox"].append(r.bbox)
+        rec["fbox"].append(r.fbox)
         rec["score"].append(r.score)
         rec["success"].append(int(r.success))
         rec["idx"].append(r.idx)
@@ -96,11 +103,45 @@ def run(cfg: str, weights: str, frames: int, seed: int, out: str, verbose=True, 
         state=np.array(rec["state"], np.float32), bbox=np.array(rec["bbox"], np.int32),
         score=np.array(rec["score"], np.float32), success=np.array(rec["success"], np.int8),
         idx=np.array(rec["idx"], np.int32), idx2=np.array(rec["idx2"], np.int32),
-        margin=np.array(rec["margin"], np.float32), gt=np.array(rec["gt"], np.int32))
+        margin=np.array(rec["margin"], np.float32), gt=np.array(rec["gt"], np.int32),
+        fbox=np.array(rec["fbox"], np.float32))
     print(f"wrote {out} ({os.path.getsize(out)} bytes)", flush=True)
 
 
+def add_fbox(name: str):
+    """re-evaluate every frame of an existing fixture from its recorded state; verify; append `fbox`"""
+    path = os.path.join(HERE, name)
+    with np.load(path) as z:
+        fx = {k: z[k] for k in z.files}
+    cfg = str(fx["config"])
+    weights = gen1_weights(cfg) if name.startswith("forced_") else vt.weights.ensure_weights(cfg)
+    assert sha256_file(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
+    hide = tuple(int(v) for v in fx["hide"]) if "hide" in fx and fx["hide"][1] > fx["hide"][0] else None
+    w, h = int(fx["frame_w"]), int(fx["frame_h"])
+    sc = vt.synth.MovingSquare(w, h, int(fx["square"]), seed=int(fx["seed"]), hide=hide)
+    trk = R.VitTrackRef(weights)
+    fbox, t0 = [], time.time()
+    for t in range(int(fx["frames"])):
+        fr = R.Frame.nv12(sc.frame_nv12(t), w, h)
+        if t == 0:
+            trk.init(fr, sc.gt_box(0))
+        trk.box = fx["state"][t].astype(np.float32).copy()
+        r = trk.update(fr)
+        assert tuple(r.bbox) == tuple(int(v) for v in fx["bbox"][t]) and r.idx == int(fx["idx"][t]) and \
+            np.float32(r.score) == fx["score"][t] and int(r.success) == int(fx["success"][t]), \
+            f"frame {t}: the oracle no longer reproduces the fixture ({r} idx {r.idx})"
+        fbox.append(r.fbox)
+        if t % 20 == 0:
+            print(f"[{name}] frame {t} fbox {r.fbox} ({time.time() - t0:.0f}s)", flush=True)
+    fx["fbox"] = np.array(fbox, np.float32)
+    np.savez_compressed(path, **fx)
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "fbox":
+        add_fbox(sys.argv[2])
+        sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["traj", "gen1head", "forced"])
     ap.add_argument("cfg", choices=sorted(CLIPS))

@@ -8,6 +8,9 @@ run does not pay seconds of CPU oracle per frame.
     guarantee (one coordinate off by one is IoU 0.969, two are 0.94): the test asserts what both
     statements allow together - every frame within +-1 px, MEAN IoU >= 0.99, min IoU >= 0.90 - and
     prints the minimum and the number of frames below 0.99.
+  * teacher-forced tests assert the FLOAT box (StreamState.last_fbox vs the fixture's `fbox`) to 0.15 px,
+    closed-loop tests the score to 0.01 on every frame whose input was bit-identical, and the number of
+    frames below IoU 0.99 may not exceed round 3's; the gen-1 head also runs CLOSED loop, bounded at +-2 px.
   * teacher-forced (open loop) on the FIRST-GENERATION noisy head (fitted on 128 CPU samples only,
     tests/golden/head_gen1_cfg3.npz): before every frame the HIP tracker's state is overwritten with
     the state the oracle had (vt_group_set_state_box), so each frame measures the divergence of ONE
@@ -65,7 +68,31 @@ BARS = {"traj_cfg3_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg3_300_b.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg2_300_b.npz": dict(px=1, min_iou=0.88, mean_iou=0.99),
         "traj_cfg5_300_b.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
+# Round 4: frames with IoU(hip, oracle) < 0.99 (a box off by one pixel in one coordinate) may not grow: bars = the
+# counts of round 3's final run (profiles/r03_gpu_tests.log) for the single tracker / the recommended-size engine.
+LOW_IOU_FRAMES = {"traj_cfg3_300.npz": (1, 1), "traj_cfg2_300.npz": (1, 1), "traj_cfg5_300.npz": (8, 22),
+                  "traj_cfg3_300_b.npz": (5, 6), "traj_cfg2_300_b.npz": (0, 0), "traj_cfg5_300_b.npz": (3, 4)}
+# result.score where both implementations evaluated the SAME input and picked the same cell: closed-loop frames
+# whose incoming state (the previous frame's integer box and success flag) is identical - then the crops are
+# bit-identical and the score differs by one forward pass's bf16 noise only (teacher-forced: <= 0.003 measured)
+SCORE_BAR_SAME_INPUT = 0.01
+FBOX_BAR_PX = 0.15      # |HIP float box - oracle float box| per coordinate on identical inputs (measured <= 0.05)
 FIXTURES = [n for n in BARS if not n.endswith("_b.npz") or os.path.exists(os.path.join(GOLD, n))]   # first clips: required
+
+
+def _same_input(boxes, succ, fx):
+    """frames of a closed-loop run on which HIP and oracle cut bit-identical crops: frame 0 (both start from
+    the ground-truth box) and every frame whose previous results agree exactly (box and success flag) - the
+    state of both is then the same integer box"""
+    prev_same = (np.abs(boxes[:-1] - fx["bbox"][:-1]).max(axis=1) == 0) & (succ[:-1] == fx["success"][:-1].astype(int))
+    # a state that was identical stays identical only while every earlier frame agreed, or a success re-synchronised
+    # it: after a success both states ARE the reported integer box, so agreement of the previous frame is enough
+    # when that frame succeeded; a lost frame keeps the older state
+    ok = np.zeros(len(boxes), bool)
+    ok[0] = True
+    for t in range(1, len(boxes)):
+        ok[t] = prev_same[t - 1] and (bool(succ[t - 1]) or ok[t - 1])
+    return ok
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -93,6 +120,7 @@ def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
     same_cell = idx == fx["idx"]
     dscore = np.abs(np.array(scores) - fx["score"])
     d = np.abs(boxes - fx["bbox"])
+    same_in = _same_input(boxes, np.array(succ), fx)
     ious = np.array([iou(tuple(a), tuple(b)) for a, b in zip(boxes, fx["bbox"])])
     gt_iou = np.array([iou(tuple(a), tuple(b)) for a, b in zip(fx["bbox"], fx["gt"])])
     with capsys.disabled():
@@ -102,9 +130,12 @@ def test_closed_loop_trajectory_vs_committed_oracle(gpu, name, capsys):
               f"min top-1/top-2 margin {fx['margin'].min():.4f}; argmax cell differs on "
               f"{(~same_cell).sum()} frames (largest oracle margin among them "
               f"{fx['margin'][~same_cell].max() if (~same_cell).any() else 0:.4f}); max |delta score| "
-              f"{dscore[same_cell].max():.4f} same cell / {dscore[~same_cell].max() if (~same_cell).any() else 0:.4f} other cell")
+              f"{dscore[same_cell].max():.4f} same cell / {dscore[~same_cell].max() if (~same_cell).any() else 0:.4f} other cell; "
+              f"{same_in.sum()} frames on bit-identical input: max |delta score| {dscore[same_in & same_cell].max():.4f}")
     assert d.max() <= bar["px"], f"max |delta| = {d.max()} px at frame {int(d.max(axis=1).argmax())}"
     assert ious.mean() >= bar["mean_iou"] and ious.min() >= bar["min_iou"]
+    assert (ious < 0.99).sum() <= LOW_IOU_FRAMES[name][0], f"{(ious < 0.99).sum()} frames below IoU 0.99 (bar {LOW_IOU_FRAMES[name][0]})"
+    assert dscore[same_in & same_cell].max() < SCORE_BAR_SAME_INPUT
     assert np.array_equal(np.array(succ), fx["success"].astype(int)), "success flags differ"
     # result.score is the raw sigmoid of the ARGMAX cell, on crops that may differ by a pixel in a
     # closed loop (and by the cell where two implementations break a near-tie differently): the bar is
@@ -148,12 +179,16 @@ def test_closed_loop_through_the_batched_large_tile_path(gpu, name, capsys):
     d = np.abs(b0 - fx["bbox"])
     ious = np.array([iou(tuple(a), tuple(b)) for a, b in zip(b0, fx["bbox"])])
     dscore = np.abs(scores[:, 0] - fx["score"])
+    same_in = _same_input(b0, succ[:, 0], fx)
     with capsys.disabled():
         print(f"\n[{name}, {B}-stream engine] {n} frames x {B} streams: max |delta| {d.max()} px, IoU(hip, oracle) min "
-              f"{ious.min():.4f} mean {ious.mean():.5f}, identical boxes: {(d.max(axis=1) == 0).sum()}, "
-              f"max |delta score| {dscore.max():.4f}; all {B} streams bit-identical to each other")
+              f"{ious.min():.4f} mean {ious.mean():.5f}, frames below 0.99: {(ious < 0.99).sum()}, identical boxes: "
+              f"{(d.max(axis=1) == 0).sum()}, max |delta score| {dscore.max():.4f} ({dscore[same_in].max():.4f} on the "
+              f"{same_in.sum()} frames with bit-identical input); all {B} streams bit-identical to each other")
     assert d.max() <= bar["px"], f"max |delta| = {d.max()} px at frame {int(d.max(axis=1).argmax())}"
     assert ious.mean() >= bar["mean_iou"] and ious.min() >= bar["min_iou"]
+    assert (ious < 0.99).sum() <= LOW_IOU_FRAMES[name][1], f"{(ious < 0.99).sum()} frames below IoU 0.99 (bar {LOW_IOU_FRAMES[name][1]})"
+    assert dscore[same_in].max() < 2 * SCORE_BAR_SAME_INPUT        # the cell may differ at a near-tie: twice the same-cell bar
     assert np.array_equal(succ[:, 0], fx["success"].astype(int)), "success flags differ"
     assert dscore.max() < 0.10
 
@@ -198,84 +233,131 @@ def test_target_lost_and_reacquired_like_the_oracle(gpu, capsys):
     assert np.abs(scores[lost] - fx["score"][lost]).max() < 0.03
 
 
+def _teacher_forced(gpu, fx, weights, engine_streams):
+    """one forward pass per frame on the oracle's own state; engine_streams = 1: the single tracker (4-wave
+    kernels), else an engine of that many streams all fed the same frame (256x256 kernels), stream 0 reported
+    after checking that every stream agrees bit for bit. Returns idx, integer boxes, scores, float boxes."""
+    sc = _clip(gpu, fx)
+    w, h, n = sc.w, sc.h, int(fx["frames"])
+    B = engine_streams
+    grp = gpu.Group(weights, n_streams=B)
+    idx, boxes, scores, fboxes = [], [], [], []
+    for t in range(n):
+        f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+        if t == 0:
+            for i in range(B):
+                grp.init_host(i, f, gpu.BBox.new(*sc.gt_box(0)))
+        for i in range(B):
+            grp.set_state_box(i, fx["state"][t])          # the oracle's state before its update of frame t
+        res = grp.update_host([f] * B)
+        assert all(r.bbox == res[0].bbox and r.score == res[0].score for r in res)
+        st = grp.read_state(0)
+        idx.append(st["last_idx"])
+        fboxes.append(st["last_fbox"])
+        boxes.append(res[0].bbox)
+        scores.append(res[0].score)
+    return np.array(idx), np.array(boxes), np.array(scores), np.array(fboxes)
+
+
+def _check_teacher_forced(fx, tag, idx, boxes, scores, fboxes, capsys):
+    assert "fbox" in fx, "fixture has no float boxes: python tests/golden/make_traj.py fbox <fixture>"
+    n = len(idx)
+    d = np.abs(boxes - fx["bbox"])
+    clear = fx["margin"] >= MARGIN_EPS
+    differ = idx != fx["idx"]
+    ds = np.abs(scores - fx["score"])
+    df = np.abs(fboxes - fx["fbox"]).max(axis=1)             # px, worst coordinate per frame
+    with capsys.disabled():
+        print(f"\n[teacher-forced, {tag}] {n} frames: frames with oracle margin < {MARGIN_EPS}: {(~clear).sum()}; argmax "
+              f"differs on {differ.sum()} frames (largest oracle margin among them "
+              f"{fx['margin'][differ].max() if differ.any() else 0:.5f}); max |delta box| {d.max()} px, identical boxes "
+              f"{(d.max(axis=1) == 0).sum()}; FLOAT box: max |delta| {df[~differ].max():.4f} px, mean {df[~differ].mean():.4f} px "
+              f"on the same cell{'' if not differ.any() else f', {df[differ].max():.4f} px on another cell'}; "
+              f"max |delta score| {ds[~differ].max():.4f}")
+    assert not (differ & clear).any(), \
+        f"argmax differs at margin {fx['margin'][differ & clear].max():.4f} (frame {int(np.argmax(differ & clear))})"
+    assert d.max() <= 1, f"open-loop box differs by {d.max()} px at frame {int(d.max(axis=1).argmax())}"
+    # the integer box hides up to a pixel of float error: on identical inputs the FLOAT boxes must agree to a
+    # fraction of a pixel wherever both decode around the same cell (a near-tie taken the other way moves the
+    # 3x3 decode window by a cell: second-order, bounded by the +-1 px above)
+    assert df[~differ].max() <= FBOX_BAR_PX, \
+        f"float box differs by {df[~differ].max():.3f} px at frame {int(np.argmax(np.where(~differ, df, 0)))}"
+    assert df.max() <= 1.0
+    assert ds[~differ].max() < SCORE_BAR_SAME_INPUT and ds.max() < 0.10
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_teacher_forced_on_the_trajectory_fixtures(gpu, name, capsys):
     """open loop on the three shipped heads: before every frame the HIP state is overwritten with the
     oracle's state of that frame (the fixture's `state`), so each of the 300 frames is ONE forward pass on
     the oracle's own input - closed-loop runs can differ in the argmax cell merely because their crops
     differ by a pixel (cfg5: 2 frames); on identical inputs the cell must be the oracle's wherever its
-    top-1/top-2 margin is >= MARGIN_EPS, the box within +-1 px, the score within 0.03 on the same cell"""
+    top-1/top-2 margin is >= MARGIN_EPS, the integer box within +-1 px, the FLOAT box (StreamState.last_fbox
+    against the fixture's `fbox`) within FBOX_BAR_PX, the score within SCORE_BAR_SAME_INPUT on the same cell.
+    Both kernel families: the single tracker and the recommended-size engine."""
     fx = _fixture(name)
     cfg = str(fx["config"])
     weights = gpu.weights.ensure_weights(cfg)
     assert _sha256(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
-    sc = _clip(gpu, fx)
-    w, h, n = sc.w, sc.h, int(fx["frames"])
-    trk = gpu.VitTrack(weights)
-    g = trk.as_group()
-    idx, boxes, scores = [], [], []
-    for t in range(n):
-        f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
-        if t == 0:
-            trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
-        g.set_state_box(0, fx["state"][t])
-        r = trk.update(f)
-        idx.append(g.read_state()["last_idx"])
-        boxes.append(r.bbox)
-        scores.append(r.score)
-    idx, boxes, scores = np.array(idx), np.array(boxes), np.array(scores)
-    d = np.abs(boxes - fx["bbox"])
-    clear = fx["margin"] >= MARGIN_EPS
-    differ = idx != fx["idx"]
-    ds = np.abs(scores - fx["score"])
-    with capsys.disabled():
-        print(f"\n[teacher-forced, {name}] {n} frames: frames with oracle margin < {MARGIN_EPS}: {(~clear).sum()}; argmax "
-              f"differs on {differ.sum()} frames (largest oracle margin among them "
-              f"{fx['margin'][differ].max() if differ.any() else 0:.5f}); max |delta box| {d.max()} px, identical boxes "
-              f"{(d.max(axis=1) == 0).sum()}; max |delta score| {ds.max():.4f}")
-    assert not (differ & clear).any(), \
-        f"argmax differs at margin {fx['margin'][differ & clear].max():.4f} (frame {int(np.argmax(differ & clear))})"
-    assert d.max() <= 1, f"open-loop box differs by {d.max()} px at frame {int(d.max(axis=1).argmax())}"
-    assert ds[~differ].max() < 0.03 and ds.max() < 0.10
+    _check_teacher_forced(fx, name, *_teacher_forced(gpu, fx, weights, 1), capsys)
+    B = gpu.weights.recommended_streams(cfg)
+    _check_teacher_forced(fx, f"{name}, {B}-stream engine", *_teacher_forced(gpu, fx, weights, B), capsys)
 
 
-def test_teacher_forced_on_the_noisy_first_generation_head(gpu, capsys):
-    fx = _fixture("forced_cfg3_300.npz")
+def _gen1_weights(gpu, fx):
     with np.load(os.path.join(GOLD, "head_gen1_cfg3.npz")) as z:
         head = {k: z[k] for k in z.files}
     weights = gpu.weights.ensure_weights(
         "cfg3", path=os.path.join(gpu.weights.default_cache_dir(), "vitb16_t192_s384_gen1head.vtw"),
         head=head)
     assert _sha256(weights) == str(fx["weights_sha256"]), "fixture was made with other weights"
+    return weights
+
+
+def test_teacher_forced_on_the_noisy_first_generation_head(gpu, capsys):
+    fx = _fixture("forced_cfg3_300.npz")
+    weights = _gen1_weights(gpu, fx)
+    idx, boxes, scores, fboxes = _teacher_forced(gpu, fx, weights, 1)
+    swapped = (idx != fx["idx"]) & (idx == fx["idx2"])           # HIP took the oracle's runner-up
+    with capsys.disabled():
+        print(f"\n[gen-1 head] oracle margin min {fx['margin'].min():.5f} median {np.median(fx['margin']):.4f}; "
+              f"{swapped.sum()} frames on the oracle's runner-up; oracle success on {int(fx['success'].sum())} frames")
+    _check_teacher_forced(fx, "gen-1 head", idx, boxes, scores, fboxes, capsys)
+    _check_teacher_forced(fx, "gen-1 head, 30-stream engine", *_teacher_forced(gpu, fx, weights, 30), capsys)
+
+
+def test_closed_loop_on_the_ill_conditioned_first_generation_head(gpu, capsys):
+    """The shipped heads are well conditioned on purpose; closed-loop parity must not rest
+    on that alone. forced_cfg3_300.npz IS the oracle's closed loop on the deliberately noisy gen-1 head (fitted
+    on 128 samples: 1-2 px of frame-to-frame jitter, top-1/top-2 margins down to 0.0008). HIP runs the same
+    clip closed loop, single tracker and 30-stream engine; the divergence is reported and BOUNDED: an
+    ill-conditioned head may turn one bf16 rounding flip into a 2-px difference for a frame before the integer
+    state re-synchronises both, so the bar here is +-2 px (and says so), at most 5 % of the frames beyond +-1 px,
+    mean IoU >= 0.98, equal success flags."""
+    fx = _fixture("forced_cfg3_300.npz")
+    weights = _gen1_weights(gpu, fx)
     sc = _clip(gpu, fx)
     w, h, n = sc.w, sc.h, int(fx["frames"])
-    trk = gpu.VitTrack(weights)
-    g = trk.as_group()
-    idx, boxes, scores = [], [], []
-    for t in range(n):
-        f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
-        if t == 0:
-            trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
-        g.set_state_box(0, fx["state"][t])          # the oracle's state before its update of frame t
-        r = trk.update(f)
-        idx.append(g.read_state()["last_idx"])
-        boxes.append(r.bbox)
-        scores.append(r.score)
-    idx, boxes = np.array(idx), np.array(boxes)
-    d = np.abs(boxes - fx["bbox"])
-    clear = fx["margin"] >= MARGIN_EPS
-    differ = idx != fx["idx"]
-    swapped = differ & (idx == fx["idx2"])           # HIP took the oracle's runner-up
-    with capsys.disabled():
-        print(f"\n[teacher-forced, gen-1 head] {n} frames: oracle margin min {fx['margin'].min():.5f} "
-              f"median {np.median(fx['margin']):.4f}, frames with margin < {MARGIN_EPS}: {(~clear).sum()}; "
-              f"argmax differs on {differ.sum()} frames ({swapped.sum()} of them = the oracle's "
-              f"runner-up), all with margin <= {fx['margin'][differ].max() if differ.any() else 0:.5f}; "
-              f"max |delta box| {d.max()} px, max |delta score| "
-              f"{np.abs(np.array(scores) - fx['score']).max():.4f}; oracle success on "
-              f"{int(fx['success'].sum())} frames")
-    assert not (differ & clear).any(), \
-        f"argmax differs at margin {fx['margin'][differ & clear].max():.4f} (frame {int(np.argmax(differ & clear))})"
-    assert d.max() <= 1, f"open-loop box differs by {d.max()} px at frame {int(d.max(axis=1).argmax())}"
-    ds = np.abs(np.array(scores) - fx["score"])
-    assert ds[~differ].max() < 0.03 and ds.max() < 0.10
+    for B in (1, 30):
+        grp = gpu.Group(weights, n_streams=B)
+        boxes, succ = [], []
+        for t in range(n):
+            f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+            if t == 0:
+                for i in range(B):
+                    grp.init_host(i, f, gpu.BBox.new(*sc.gt_box(0)))
+            res = grp.update_host([f] * B)
+            assert all(r.bbox == res[0].bbox for r in res)
+            boxes.append(res[0].bbox)
+            succ.append(int(res[0].success))
+        boxes = np.array(boxes)
+        d = np.abs(boxes - fx["bbox"]).max(axis=1)
+        ious = np.array([iou(tuple(a), tuple(b)) for a, b in zip(boxes, fx["bbox"])])
+        with capsys.disabled():
+            print(f"\n[closed loop, gen-1 head, {B} stream(s)] {n} frames: identical boxes {(d == 0).sum()}, off by 1 px "
+                  f"{(d == 1).sum()}, by 2 px {(d == 2).sum()}, more {(d > 2).sum()} (first at frame "
+                  f"{int(np.argmax(d > 1)) if (d > 1).any() else -1}); IoU min {ious.min():.4f} mean {ious.mean():.5f}, "
+                  f"frames below 0.99: {(ious < 0.99).sum()}")
+        assert d.max() <= 2, f"closed loop on the gen-1 head diverged by {d.max()} px at frame {int(d.argmax())}"
+        assert (d > 1).sum() <= 0.05 * n and ious.mean() >= 0.98
+        assert np.array_equal(np.array(succ), fx["success"].astype(int)), "success flags differ"
