@@ -64,6 +64,17 @@ __device__ __forceinline__ f32x4_t mma16(const bf16x8_t& xa, const bf16x8_t& wb,
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, c, 0, 0, 0);
 }
 
+// tuning builds only (VT_AB_ANT): the A operand's LDS-DMA with the non-temporal hint (aux = 2), so that a
+// streamed row panel does not push the W tiles an XCD keeps re-reading out of its L2
+#ifdef VT_AB_ANT
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+}
+#define G256_GLDS_A glds16_nt
+#else
+#define G256_GLDS_A glds16
+#endif
 #define G256_RD(ptr, off) (*reinterpret_cast<const bf16x8_t*>((ptr) + (off)))
 
 // LDS accesses of the persistent kernel's wave-private epilogue, as inline asm: hipcc (ROCm 7.2) puts
@@ -106,8 +117,8 @@ __device__ __forceinline__ void lds_wait2_asm(u32x4_t& a, u32x4_t& b) {
     {                                                                                            \
         const char* s_ = reinterpret_cast<const char*>(p.A) + (size_t)(KT) * 128;                \
         char* d_ = smem + (BO) + (I) * G256_HALF + wave * 1024;                                  \
-        glds16(s_ + ((I) ? aoff10 : aoff00), d_);                                                \
-        glds16(s_ + ((I) ? aoff11 : aoff01), d_ + 8192);                                         \
+        G256_GLDS_A(s_ + ((I) ? aoff10 : aoff00), d_);                                           \
+        G256_GLDS_A(s_ + ((I) ? aoff11 : aoff01), d_ + 8192);                                    \
     }
 #define G256_STAGE_B(J, KT, BO)                                                                  \
     {                                                                                            \
@@ -448,7 +459,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
             if constexpr (EPI == EPI_RESID) {
                 a0 = *reinterpret_cast<const u32x4_t*>(p.Xh + (size_t)mc * p.ldx + n8);
+#ifdef VT_AB_NOLO    /* tuning builds only: upper bound of what cutting the pair's bytes can buy (wrong results) */
+                a1 = u32x4_t{0u, 0u, 0u, 0u};
+#elif defined(VT_AB_LO8)
+                { const uint2 t2 = *reinterpret_cast<const uint2*>(p.Xl + (size_t)mc * p.ldx + n8); a1 = u32x4_t{t2.x, t2.y, 0u, 0u}; }
+#else
                 a1 = *reinterpret_cast<const u32x4_t*>(p.Xl + (size_t)mc * p.ldx + n8);
+#endif
             } else if constexpr (EPI == EPI_F32_POS) {
                 const float* src = p.pos + (size_t)(mc % p.pos_rows) * p.ldx + n8;
                 a0 = *reinterpret_cast<const u32x4_t*>(src);
@@ -495,7 +512,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 x_split8(x, hi, lo);
                 if (m < p.M) {
                     *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
+#ifdef VT_AB_NOLO
+                    asm volatile("" :: "v"(lo));
+#elif defined(VT_AB_LO8)   /* tuning builds only: an 8-byte store in place of the 16-byte one (timing of a 3-B format) */
+                    *reinterpret_cast<uint2*>(p.Xl + (size_t)m * p.ldx + n8) = make_uint2(lo[0], lo[1]);
+#else
                     *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
+#endif
                 }
                 // chunk partials: two chunks (this quad's and the next one's, fetched from lane + 4) per 16-B
                 // WRITE-THROUGH (sc1) store - the row panel's last workgroup may read them in this launch
@@ -845,9 +868,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     // and dropped the alternative of an XCD OWNING a column group and a quarter of its tiles for the whole
     // launch - W panels resident in its L2, every A panel fetched by one XCD per group: fc1 at 30 streams
     // 105.7 us against 100.5 with this dealing, ViT-L fc1 283 against 286: profiles/r03_tile_order_ab.txt.)
+#ifdef VT_AB_OWN     /* tuning builds only: an XCD owns a column group and a contiguous share of its tiles */
+    const int groups_ = (p.N >> 8) / cgw, xpg_ = 8 / (groups_ > 0 && groups_ <= 8 && 8 % groups_ == 0 ? groups_ : 8);
+    const int per_x_ = (per_group + xpg_ - 1) / xpg_;
+    const bool own_ = groups_ > 0 && groups_ <= 8 && 8 % groups_ == 0;
+    int seq = own_ ? (xcd / xpg_) * per_group + (xcd % xpg_) * per_x_ + slot : xcd * 32 + slot;
+    const int seq_step = own_ ? 32 : 8 * 32;
+    const int own_end_ = (xcd / xpg_) * per_group + ((xcd % xpg_ + 1) * per_x_ < per_group ? (xcd % xpg_ + 1) * per_x_ : per_group);
+    const int seq_end = own_ ? own_end_ : tiles;
+#else
     int seq = xcd * 32 + slot;                 // round 0: chunk xcd
     const int seq_step = 8 * 32;               // next round: chunk + 8
     const int seq_end = tiles;
+#endif
     (void)per_round;
     int m0 = 0, n0 = 0;
     bool after16 = false;
@@ -1061,11 +1094,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
             const uint32_t wa10 = wb_ + (((8 + eq) ^ wsw) << 3), wa11 = wb_ + (((12 + eq) ^ wsw) << 3);
             const uint32_t ra = lds_addr(ow) + rr * 128 + ((rc ^ rr) << 4);
             u32x4_t o0, o1;
+// Output stores of the persistent kernel are WRITE-THROUGH (sc1): a plain store keeps its line in the XCD's
+// L2 (MI355X guide, "stores of each flavour"), and a round's 32 output tiles per XCD are 4.2 MB - as much as the
+// round's operand tiles - pushed through a 4-MiB L2 that the 32 CUs are re-reading those operands from.
+// Round 4, alternating builds in one process (profiles/r04_fc1_tile_order_cache_policy.txt): fc1 100.5 -> 96.3 us,
+// QKV 70.8 -> 69.4 us, ViT-L fc1 281.5 -> 277.2 us; fabric reads 151.7 -> 145.5 MB. VT_AB_PLAINOUT: the old form.
+#ifndef VT_AB_PLAINOUT
+#define G256P_ST16(PTR, V) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(PTR), "v"(V) : "memory")
+#else
+#define G256P_ST16(PTR, V) *reinterpret_cast<u32x4_t*>(PTR) = (V)
+#endif
 #define G256P_STORE(KB)                                                                           \
     lds_wait2_asm(o0, o1);                                                                       \
     if (full) {                                                                                  \
-        *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0;                 \
-        *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1;             \
+        G256P_ST16(obase + (size_t)((KB) * 2) * ostride8, o0);                                   \
+        G256P_ST16(obase + (size_t)((KB) * 2 + 1) * ostride8, o1);                               \
     } else {                                                                                     \
         if ((KB) * 16 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0; \
         if ((KB) * 16 + 8 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1; \
@@ -1114,6 +1157,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
 #undef G256P_EPI_BLOCK
 #undef G256P_EPI_ONE
 #undef G256P_STORE
+#undef G256P_ST16
             // queue of this wave now: g g | s s g g | s s g g | s s g g | s s g g | s s g g | s s | s s | s s
             after16 = more && full;
         } else if constexpr (EPI == EPI_QKV) {
