@@ -185,6 +185,9 @@ extern "C" {
     pub fn vt_release_dmabuf(m: *mut vt_extmem);
     pub fn vt_export_dmabuf(device_id: c_int, d_ptr: *const c_void, bytes: usize, fd_out: *mut c_int) -> c_int;
 
+    pub fn vt_host_register(device_id: c_int, host_ptr: *mut c_void, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
+    pub fn vt_host_unregister(device_id: c_int, host_ptr: *mut c_void) -> c_int;
+
     pub fn vt_nv12_to_rgb8(device_id: c_int, nv12: *const u8, len: usize, w: c_int, h: c_int, rgb_out: *mut u8) -> c_int;
     pub fn vt_nv12_to_rgb8_device(device_id: c_int, d_nv12: *const c_void, len: usize, w: c_int, h: c_int, d_rgb_out: *mut c_void, hip_stream: *mut c_void) -> c_int;
 

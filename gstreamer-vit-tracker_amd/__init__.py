@@ -84,7 +84,7 @@ EXPORTS = [
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
-    "vt_recommended_streams", "vt_plan_engines", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
+    "vt_recommended_streams", "vt_plan_engines", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_host_register", "vt_host_unregister", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
     "vt_group_host_redos", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
@@ -131,6 +131,8 @@ def lib():
                                       CBBox]
     L.vt_update_nv12_device.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         POINTER(CResult)]
+    L.vt_host_register.argtypes = [c_int, c_void_p, c_size_t, POINTER(c_void_p)]
+    L.vt_host_unregister.argtypes = [c_int, c_void_p]
     L.vt_group_create.argtypes = [c_char_p, c_int, POINTER(CConfig), POINTER(c_void_p)]
     L.vt_group_create_from_device_blob.argtypes = [c_void_p, c_size_t, c_int, POINTER(CConfig),
                                                    POINTER(c_void_p)]
@@ -242,6 +244,29 @@ def export_dmabuf(d_ptr: int, nbytes: int, device: int = 0) -> int:
     fd = c_int(-1)
     _check(lib().vt_export_dmabuf(device, d_ptr, nbytes, byref(fd)))
     return fd.value
+
+
+class HostMapping:
+    """A host buffer (NumPy array) page-locked and mapped into the device's address space
+    (vt_host_register): `.d_ptr` + offset serves as plane pointers of frame_nv12 / frame_rgb8 with the
+    *_device entry points - the pixel kernel reads only the pixels it samples over PCIe."""
+
+    def __init__(self, arr: np.ndarray, device: int = 0):
+        self.arr, self.device, self.d_ptr = arr, device, None
+        dp = c_void_p()
+        _check(lib().vt_host_register(device, c_void_p(arr.ctypes.data), arr.nbytes, byref(dp)))
+        self.d_ptr = dp.value
+
+    def close(self):
+        if self.d_ptr is not None:
+            lib().vt_host_unregister(self.device, c_void_p(self.arr.ctypes.data))
+            self.d_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def rccl_unique_id() -> bytes:

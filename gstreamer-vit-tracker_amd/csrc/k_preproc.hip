@@ -344,7 +344,19 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     }
     const int tiles_x = size / PRE_TILE_W;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int oy = ty * PRE_TILE_H + (threadIdx.x >> 3), ox0 = tx * PRE_TILE_W + (threadIdx.x & 7) * PX;
+    // lane -> 8-pixel run of the tile. patch 16 (round 4): the tile is 4 x 2 tokens and a half-wave takes ONE
+    // token - lane pair (2 py, 2 py + 1) of 16 patch rows - so that a channel's store instruction writes the
+    // 512 contiguous bytes of that token's channel block instead of 16-B pieces of four different patch rows
+    // (rows of the patch matrix lie kpad * 2 bytes apart); other patch sizes keep the row-major assignment.
+    int oy, ox0;
+    if (patch == 16) {
+        const int tok = threadIdx.x >> 5, py = (threadIdx.x >> 1) & 15, hx = threadIdx.x & 1;
+        oy = ty * PRE_TILE_H + (tok >> 2) * 16 + py;
+        ox0 = tx * PRE_TILE_W + (tok & 3) * 16 + hx * PX;
+    } else {
+        oy = ty * PRE_TILE_H + (threadIdx.x >> 3);
+        ox0 = tx * PRE_TILE_W + (threadIdx.x & 7) * PX;
+    }
     // source rectangle of the tile: taps of its first and last output pixel (fx, fy grow with ox, oy)
     const int sx_lo = (int)floorf(((float)(tx * PRE_TILE_W) + 0.5f) * scale + x0m);
     const int sx_hi = (int)floorf(((float)(tx * PRE_TILE_W + PRE_TILE_W - 1) + 0.5f) * scale + x0m) + 1;
@@ -354,11 +366,53 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     const bool staged = sw > 0 && sh > 0 && sw * sh <= PRE_TILE_LDS;      // block-uniform
     if (staged) {
         const int n = (int)(sw * sh), w_ = (int)sw;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            float p[3];
-            int miss = 0;
-            fetch_rgb(f, sx_lo + i % w_, sy_lo + i / w_, p, miss);
-            src[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)miss << 24);
+        // NV12 planes whose rows start on 8-byte boundaries (the library's packed windows: pack_window; whole
+        // frames with such strides): the rectangle is fetched in groups of 8 pixels - ONE 8-byte load of Y
+        // and ONE of the interleaved UV row (4 pairs) per group, where the per-pixel path issues 24 byte
+        // loads - and converted with the same integer formulas. A group that is not entirely inside the
+        // frame and the stored window goes through fetch_rgb pixel by pixel (frame border: black; outside the
+        // window: black + miss), so every entry of the LDS image is what the per-pixel loop writes.
+        const bool fast = f.fmt == VT_PIX_NV12 && (((uintptr_t)f.p0 | (uintptr_t)f.p1 | (uintptr_t)f.s0 | (uintptr_t)f.s1) & 7) == 0;
+        if (fast) {
+            const int g_lo = (sx_lo - f.x0) >> 3, g_hi = (sx_hi - f.x0) >> 3;     // arithmetic shift: floor for negatives
+            const int gpr = g_hi - g_lo + 1, ng = gpr * (int)sh;
+            for (int i = threadIdx.x; i < ng; i += 256) {
+                const int ry = i / gpr, wx0 = (g_lo + i % gpr) << 3;                // window column of the group
+                const int py = sy_lo + ry, wy_ = py - f.y0, px0 = wx0 + f.x0;
+                const bool inside = (unsigned)wy_ < (unsigned)f.wh && (unsigned)py < (unsigned)f.h && wx0 >= 0 &&
+                                    wx0 + 7 < f.ww && px0 >= 0 && px0 + 7 < f.w;
+                uint32_t* dst = src + ry * w_ + (px0 - sx_lo);
+                if (inside) {
+                    const uint2 y8 = *reinterpret_cast<const uint2*>(f.p0 + (size_t)wy_ * f.s0 + wx0);
+                    const uint2 uv8 = *reinterpret_cast<const uint2*>(f.p1 + (size_t)(wy_ >> 1) * f.s1 + wx0);
+                    const uint32_t yw[2] = {y8.x, y8.y}, uw[2] = {uv8.x, uv8.y};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int col = px0 - sx_lo + k;
+                        if (col < 0 || col >= w_) continue;
+                        const uint32_t pair = uw[k >> 2] >> (((k >> 1) & 1) * 16);   // U, V of the pixel pair
+                        int r, g, b;
+                        yuv_to_rgb((int)((yw[k >> 2] >> ((k & 3) * 8)) & 255u), (int)(pair & 255u), (int)((pair >> 8) & 255u), r, g, b);
+                        dst[k] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+                    }
+                } else {
+                    for (int k = 0; k < 8; ++k) {
+                        const int col = px0 - sx_lo + k;
+                        if (col < 0 || col >= w_) continue;
+                        float p[3];
+                        int miss = 0;
+                        fetch_rgb(f, px0 + k, py, p, miss);
+                        dst[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)miss << 24);
+                    }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                float p[3];
+                int miss = 0;
+                fetch_rgb(f, sx_lo + i % w_, sy_lo + i / w_, p, miss);
+                src[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)miss << 24);
+            }
         }
         __syncthreads();
     }

@@ -935,6 +935,33 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
     return VT_OK;
 } VT_NOTHROW_INT
 
+int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr) try {
+    if (!host_ptr || !d_ptr || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    *d_ptr = nullptr;
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    hipError_t he = hipHostRegister(host_ptr, bytes, hipHostRegisterMapped);
+    if (he != hipSuccess) return set_err(VT_ERR_HIP, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(he));
+    void* dp = nullptr;
+    he = hipHostGetDevicePointer(&dp, host_ptr, 0);
+    if (he != hipSuccess || !dp) {
+        (void)hipHostUnregister(host_ptr);
+        return set_err(VT_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(he));
+    }
+    *d_ptr = dp;
+    return VT_OK;
+} VT_NOTHROW_INT
+
+int vt_host_unregister(int device_id, void* host_ptr) try {
+    if (!host_ptr) return set_err(VT_ERR_INVALID_ARG, "null pointer");
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
+    hipError_t he = hipHostUnregister(host_ptr);
+    if (he != hipSuccess) return set_err(VT_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(he));
+    return VT_OK;
+} VT_NOTHROW_INT
+
 int vt_recommended_streams(const vt_model_info* info, int max_streams) try {
     if (!info || info->dim <= 0 || (info->dim % 256) != 0 || max_streams < 1) return 1;
     const long tokens = (long)info->tokens_template + info->tokens_search;
@@ -1301,9 +1328,11 @@ static int plan_window(const Engine* e, int fmt, const uint8_t* p0, const uint8_
     win->x_lo = (int)x_lo; win->y_lo = (int)y_lo;
     win->ww = (int)(x_hi - x_lo); win->wh = (int)(y_hi - y_lo);
     if (fmt == VT_PIX_NV12) {
-        const int uvw = (win->ww + 1) & ~1, uvh = (win->wh + 1) / 2;
-        win->uv_off = ((size_t)win->ww * win->wh + 255) & ~(size_t)255;
-        win->bytes = win->uv_off + (size_t)uvw * uvh;
+        // rows of the packed window start on 16-byte boundaries: the pixel kernel then fetches 8 pixels per load
+        const int uvh = (win->wh + 1) / 2;
+        const size_t ys = ((size_t)win->ww + 15) & ~(size_t)15, uvs = ((size_t)((win->ww + 1) & ~1) + 15) & ~(size_t)15;
+        win->uv_off = (ys * win->wh + 255) & ~(size_t)255;
+        win->bytes = win->uv_off + uvs * uvh;
     } else {
         win->uv_off = 0;
         win->bytes = (size_t)win->ww * win->wh * (fmt == VT_PIX_RGB8 ? 3 : 2);
@@ -1352,15 +1381,16 @@ static void pack_window(const Arena& a, const HostWin& wn, size_t off, vt_frame*
         f->plane0 = *a.d + off; f->stride0 = (int)rb;
     } else {
         const int uvw = (wn.ww + 1) & ~1, uvh = (wn.wh + 1) / 2;
+        const size_t ys = ((size_t)wn.ww + 15) & ~(size_t)15, uvs = ((size_t)uvw + 15) & ~(size_t)15;   // as plan_window
         for (int r = 0; r < wn.wh; ++r)
-            memcpy(dst + (size_t)r * wn.ww, wn.p0 + (size_t)(wn.y_lo + r) * wn.s0 + wn.x_lo, (size_t)wn.ww);
+            memcpy(dst + (size_t)r * ys, wn.p0 + (size_t)(wn.y_lo + r) * wn.s0 + wn.x_lo, (size_t)wn.ww);
         // odd frame width: the last pixel's V byte lies one past the row's last full pair
         const int uv_avail = (int)std::min<long>(uvw, (long)wn.s1 - wn.x_lo);
         for (int r = 0; r < uvh; ++r)
-            memcpy(dst + wn.uv_off + (size_t)r * uvw, wn.p1 + (size_t)(wn.y_lo / 2 + r) * wn.s1 + wn.x_lo,
+            memcpy(dst + wn.uv_off + (size_t)r * uvs, wn.p1 + (size_t)(wn.y_lo / 2 + r) * wn.s1 + wn.x_lo,
                    (size_t)uv_avail);
         f->plane0 = *a.d + off; f->plane1 = *a.d + off + wn.uv_off;
-        f->stride0 = wn.ww; f->stride1 = uvw;
+        f->stride0 = (int)ys; f->stride1 = (int)uvs;
     }
 }
 

@@ -265,6 +265,17 @@ void vt_release_dmabuf(vt_extmem* m);
  * caller closes the fd). Tooling: used by the tests to exercise the import path on this machine. */
 int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out);
 
+/* ---- zero-copy ingest of host frames --------------------------------------------------------------
+ * The reference maps the capture buffer on the CPU (src/pipeline.rs:95-101) and hands the tracker a view
+ * of the whole frame, of which the tracker samples one window. vt_host_register page-locks such a buffer
+ * (typically the capture pool, once at start-up) and maps it into the device's address space
+ * (hipHostRegister + hipHostGetDevicePointer): *d_ptr + offset may then be used as plane0 / plane1 of a
+ * vt_frame with the *_device entry points, and the pixel kernel reads only the pixels it samples over
+ * PCIe - no staging copy, no packing on the CPU, whatever the frame size. The memory stays owned by the
+ * caller; unregister before freeing it. */
+int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr);
+int vt_host_unregister(int device_id, void* host_ptr);
+
 /* ---- reference colour converter on the GPU ---------------------------------------------- */
 
 /* ≙ nv12_full_to_rgb_parallel(nv12_data, width, height) (src/nv12_convert.rs:46-92): packed NV12

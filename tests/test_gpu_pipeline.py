@@ -698,3 +698,40 @@ def test_pipelined_host_passes_equal_synchronous_ones(gpu, weights_tiny, margin_
         assert after[i]["frames_done"] == before[i]["frames_done"] or after[i]["frames_done"] == n + 2
     # the synchronous entry point still works afterwards and continues the same state chain
     assert len(pipe.update_host(frames[2])) == B
+
+
+def test_zero_copy_host_mapping_tracks_like_device_frames(gpu, oracle, weights_tiny):
+    """vt_host_register: frames stay in (page-locked, device-mapped) host memory and the pixel kernel reads
+    what it samples over PCIe. Same results, bit for bit, as the same frames resident in HBM - single
+    tracker and a group; the patch matrix of the last update is bit-exact with the oracle's."""
+    import torch
+    w, h, n = 640, 480, 10
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=17)
+    clip = np.stack([sc.frame_nv12(t) for t in range(n)])
+    fb = clip.shape[1]
+    dclip = torch.from_numpy(clip).cuda()
+    hm = gpu.HostMapping(clip)
+    assert hm.d_ptr
+    try:
+        fr_d = lambda t: gpu.frame_nv12(dclip.data_ptr() + t * fb, dclip.data_ptr() + t * fb + w * h, w, h)
+        fr_z = lambda t: gpu.frame_nv12(hm.d_ptr + t * fb, hm.d_ptr + t * fb + w * h, w, h)
+        ga, gb = gpu.Group(weights_tiny, n_streams=2), gpu.Group(weights_tiny, n_streams=2)
+        for i in range(2):
+            ga.init_device(i, fr_d(0), gpu.BBox.new(*sc.gt_box(0)))
+            gb.init_device(i, fr_z(0), gpu.BBox.new(*sc.gt_box(0)))
+        for t in range(n):
+            ra, rb = ga.update_device([fr_d(t)] * 2), gb.update_device([fr_z(t)] * 2)
+            assert [(r.bbox, r.score, r.success) for r in ra] == [(r.bbox, r.score, r.success) for r in rb], t
+        mi = ga.model_info()
+        pa = ga.read_tensor("patches").reshape(-1, mi.kpad)
+        pb = gb.read_tensor("patches").reshape(-1, mi.kpad)
+        assert np.array_equal(pa, pb)
+        trk = gpu.VitTrack.new(weights_tiny)
+        trk.init_nv12_device(hm.d_ptr, hm.d_ptr + w * h, w, h, w, w, gpu.BBox.new(*sc.gt_box(0)))
+        r = trk.update_nv12_device(hm.d_ptr + fb, hm.d_ptr + fb + w * h, w, h, w, w)
+        assert r.success
+    finally:
+        del ga, gb
+        hm.close()
+    with pytest.raises(gpu.VtError):
+        gpu.HostMapping(np.zeros(0, np.uint8))
