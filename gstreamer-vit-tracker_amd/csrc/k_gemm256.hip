@@ -1114,32 +1114,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         if ((KB) * 16 + 8 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1; \
     }
 #ifdef VT_AB_SCALAR_GELU      /* tuning builds only: the per-element form, for A/B against the packed one */
-#define VT_GELU2(X) f32v2_t{gelu_erf((X).x), gelu_erf((X).y)}
+#define VT_GELU2X4(V) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) V[e_] = f32v2_t{gelu_erf(V[e_].x), gelu_erf(V[e_].y)}; }
 #else
-#define VT_GELU2(X) gelu_erf2(X)
+#define VT_GELU2X4(V) gelu_erf2x4(V)
 #endif
-#define G256P_EPI_ONE(K, J, NF, WA)                                                              \
+// the four 2 x 2-element groups of a block are computed FIRST and written to LDS afterwards: an asm statement is
+// a scheduling fence, and with one ds_write per group hipcc had only that group's two dependent chains to
+// interleave - 218 s_nop (packed-fma result -> next packed fma, v_exp -> use) per tile and wave in a section
+// that is bound by vector issue. With eight independent chains per block the hazards are covered by real work.
+#define G256P_EPI_X(K, J, NF, E)                                                                 \
+    __builtin_elementwise_fma(f32v2_t{rs8[K].x, rs8[K].x},                                       \
+        f32v2_t{acc[(K) >> 2][(K) & 3][J][NF][2 * (E)], acc[(K) >> 2][(K) & 3][J][NF][2 * (E) + 1]}, \
+        __builtin_elementwise_fma(f32v2_t{rs8[K].y, rs8[K].y}, f32v2_t{cs4[J][NF][2 * (E)], cs4[J][NF][2 * (E) + 1]}, \
+                                  f32v2_t{bias4[J][NF][2 * (E)], bias4[J][NF][2 * (E) + 1]}))
+#define G256P_EPI_CALC2(K, J, LO0, HI0, LO1, HI1)                                                \
     {                                                                                            \
-        f32v2_t v[2];                                                                            \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                          \
-            const f32v2_t t = __builtin_elementwise_fma(f32v2_t{rs8[K].y, rs8[K].y},                  \
-                                                        f32v2_t{cs4[J][NF][2 * e], cs4[J][NF][2 * e + 1]}, \
-                                                        f32v2_t{bias4[J][NF][2 * e], bias4[J][NF][2 * e + 1]}); \
-            const f32v2_t x = __builtin_elementwise_fma(f32v2_t{rs8[K].x, rs8[K].x},                  \
-                f32v2_t{acc[(K) >> 2][(K) & 3][J][NF][2 * e], acc[(K) >> 2][(K) & 3][J][NF][2 * e + 1]}, t); \
-            if constexpr (EPI == EPI_GELU_BF16) v[e] = VT_GELU2(x);                              \
-            else if constexpr (EPI == EPI_RELU_BF16) v[e] = f32v2_t{fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)}; \
-            else v[e] = x * scale;                                                               \
+        f32v2_t v[4] = {G256P_EPI_X(K, J, 0, 0), G256P_EPI_X(K, J, 0, 1), G256P_EPI_X(K, J, 1, 0), G256P_EPI_X(K, J, 1, 1)}; \
+        if constexpr (EPI == EPI_GELU_BF16) {                                                    \
+            VT_GELU2X4(v);                                                                       \
+        } else if constexpr (EPI == EPI_RELU_BF16) {                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = f32v2_t{fmaxf(v[e].x, 0.0f), fmaxf(v[e].y, 0.0f)}; \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = v[e] * scale;                    \
         }                                                                                        \
-        lds_write64_asm<((K) & 1) * 2048>(WA, __builtin_bit_cast(uint32_t, __builtin_convertvector(v[0], bf16v2_t)), \
-                                          __builtin_bit_cast(uint32_t, __builtin_convertvector(v[1], bf16v2_t))); \
+        LO0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[0], bf16v2_t));             \
+        HI0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[1], bf16v2_t));             \
+        LO1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[2], bf16v2_t));             \
+        HI1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[3], bf16v2_t));             \
     }
 #define G256P_EPI_BLOCK(K, STAGE_STMT)                                                           \
     {                                                                                            \
-        G256P_EPI_ONE(K, 0, 0, wa00)                                                             \
-        G256P_EPI_ONE(K, 0, 1, wa01)                                                             \
-        G256P_EPI_ONE(K, 1, 0, wa10)                                                             \
-        G256P_EPI_ONE(K, 1, 1, wa11)                                                             \
+        uint32_t l00, h00, l01, h01, l10, h10, l11, h11;                                         \
+        G256P_EPI_CALC2(K, 0, l00, h00, l01, h01)                                                \
+        G256P_EPI_CALC2(K, 1, l10, h10, l11, h11)                                                \
+        lds_write64_asm<((K) & 1) * 2048>(wa00, l00, h00);                                       \
+        lds_write64_asm<((K) & 1) * 2048>(wa01, l01, h01);                                       \
+        lds_write64_asm<((K) & 1) * 2048>(wa10, l10, h10);                                       \
+        lds_write64_asm<((K) & 1) * 2048>(wa11, l11, h11);                                       \
         if ((K) > 0) { G256P_STORE((K) - 1) }                                                    \
         if (more) { STAGE_STMT }                                                                 \
         lds_read128_asm<((K) & 1) * 2048>(o0, ra);                                               \
@@ -1155,7 +1166,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
             G256P_EPI_BLOCK(7, )
             G256P_STORE(7)
 #undef G256P_EPI_BLOCK
-#undef G256P_EPI_ONE
+#undef G256P_EPI_CALC2
+#undef G256P_EPI_X
 #undef G256P_STORE
 #undef G256P_ST16
             // queue of this wave now: g g | s s g g | s s g g | s s g g | s s g g | s s g g | s s | s s | s s

@@ -43,6 +43,32 @@ __device__ __forceinline__ f32v2_t gelu_erf2(f32v2_t x) {
     return __builtin_elementwise_fma(-a, e, r);
 }
 
+// gelu_erf2 on FOUR element pairs in lock step (step k of every pair before step k + 1 of any): a packed fma
+// result needs a wait state before the next packed fma reads it, and v_exp before its use; written pair after
+// pair hipcc pads every dependent step with s_nop (216 per 128 elements in the persistent GEMM's epilogue,
+// a section bound by vector issue). Each element's result is bit-identical to gelu_erf's.
+__device__ __forceinline__ void gelu_erf2x4(f32v2_t (&x)[4]) {
+    f32v2_t a[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = f32v2_t{fabsf(x[i].x), fabsf(x[i].y)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        p[i] = __builtin_elementwise_fma(f32v2_t{-0.0004733149544335902f, -0.0004733149544335902f}, a[i],
+                                         f32v2_t{0.007084596436470747f, 0.007084596436470747f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], a[i], f32v2_t{-0.05182747542858124f, -0.05182747542858124f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], a[i], f32v2_t{-0.45999234914779663f, -0.45999234914779663f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], a[i], f32v2_t{-1.1507878303527832f, -1.1507878303527832f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], a[i], f32v2_t{-1.000037670135498f, -1.000037670135498f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = f32v2_t{__builtin_amdgcn_exp2f(p[i].x), __builtin_amdgcn_exp2f(p[i].y)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_fma(-a[i], p[i], f32v2_t{fmaxf(x[i].x, 0.0f), fmaxf(x[i].y, 0.0f)});
+}
+
 // A 4-B global load the compiler neither moves nor waits for: the caller puts an
 // `s_waitcnt vmcnt(..)` (with the destination as an in/out operand) before the first use and does not
 // touch the value in between.

@@ -312,10 +312,14 @@ __global__ __launch_bounds__(256) void preproc_wide_kernel(const FrameDesc* __re
 // before), kept in LDS as r | g << 8 | b << 16 | miss << 24, and the lanes interpolate from LDS. A
 // tap that lay outside the stored window still raises window_miss only if an output pixel uses it.
 // Same arithmetic, same order: bit-exact with the other kernels and the oracle. Rectangles that do
-// not fit the 32 KiB buffer (very large targets) take the direct fetches of the wide kernel.
+// not fit the 16 KiB buffer (very large targets) take the direct fetches of the wide kernel.
 #define PRE_TILE_W 64
 #define PRE_TILE_H 32
-#define PRE_TILE_LDS 8192       // source pixels (32 KiB)
+// 16 KiB of LDS per block: eight 256-thread blocks per CU (the thread limit), so the 2,160 blocks of a
+// 30-stream pass are resident at once - a block is one dependent chain (descriptor -> state -> fetch -> LDS ->
+// interpolate -> store, ~7 us) and with 32 KiB (5 blocks per CU) the pass took two rounds of it. A 64-px target
+// at 1080p needs ~1,000 source pixels per tile, a 128-px one ~3,900.
+#define PRE_TILE_LDS 4096       // source pixels (16 KiB)
 __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __restrict__ frames,
                                                            StreamState* __restrict__ states,
                                                            bf16_t* __restrict__ patches, int b0,
@@ -421,44 +425,59 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     const float wy = fy - fy0;
     const int iy = (int)fy0;
     const float na[3] = {na0, na1, na2}, nb[3] = {nb0, nb1, nb2};
-    bf16_t o[3][PX];
+    const int grid = size / patch;
+    const int token = (oy / patch) * grid + (ox0 / patch);         // PX divides patch: one token per group
+    const int kin = (oy % patch) * patch + (ox0 % patch);
+    bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
     int miss = 0;
+    if (!staged) {
+        // rare (targets of several hundred pixels): direct fetches, pixel by pixel, 2-byte stores. Kept out of
+        // the staged path's code: inlined into its unrolled loop the 32 fetch_rgb bodies cost 70 VGPRs and
+        // with them a block per CU.
+#pragma unroll 1
+        for (int k = 0; k < PX; ++k) {
+            const float fx = ((float)(ox0 + k) + 0.5f) * scale + x0m;
+            const float fx0 = floorf(fx);
+            const float wx = fx - fx0;
+            const int ix = (int)fx0;
+            float p00[3], p01[3], p10[3], p11[3];
+            fetch_rgb(f, ix, iy, p00, miss);
+            fetch_rgb(f, ix + 1, iy, p01, miss);
+            fetch_rgb(f, ix, iy + 1, p10, miss);
+            fetch_rgb(f, ix + 1, iy + 1, p11, miss);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float top = p00[c] + wx * (p01[c] - p00[c]);
+                const float bot = p10[c] + wx * (p11[c] - p10[c]);
+                const float v = top + wy * (bot - top);
+                row[c * patch * patch + kin + k] = f32_to_bf16(v * na[c] + nb[c]);
+            }
+        }
+        if (miss && !is_template) s.window_miss = s.frames_done + 1;
+        return;
+    }
+    bf16_t o[3][PX];
+    const int w_ = (int)sw;
+    const uint32_t* r0base = src + (iy - sy_lo) * w_ - sx_lo;
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
         const float fx = ((float)(ox0 + k) + 0.5f) * scale + x0m;
         const float fx0 = floorf(fx);
         const float wx = fx - fx0;
-        const int ix = (int)fx0;
-        float p00[3], p01[3], p10[3], p11[3];
-        if (staged) {
-            const int w_ = (int)sw;
-            const uint32_t* r0 = src + (iy - sy_lo) * w_ + (ix - sx_lo);
-            const uint32_t t00 = r0[0], t01 = r0[1], t10 = r0[w_], t11 = r0[w_ + 1];
-            miss |= (int)((t00 | t01 | t10 | t11) >> 24);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                p00[c] = (float)((t00 >> (8 * c)) & 255u); p01[c] = (float)((t01 >> (8 * c)) & 255u);
-                p10[c] = (float)((t10 >> (8 * c)) & 255u); p11[c] = (float)((t11 >> (8 * c)) & 255u);
-            }
-        } else {
-            fetch_rgb(f, ix, iy, p00, miss);
-            fetch_rgb(f, ix + 1, iy, p01, miss);
-            fetch_rgb(f, ix, iy + 1, p10, miss);
-            fetch_rgb(f, ix + 1, iy + 1, p11, miss);
-        }
+        const uint32_t* r0 = r0base + (int)fx0;
+        const uint32_t t00 = r0[0], t01 = r0[1], t10 = r0[w_], t11 = r0[w_ + 1];
+        miss |= (int)((t00 | t01 | t10 | t11) >> 24);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float top = p00[c] + wx * (p01[c] - p00[c]);
-            const float bot = p10[c] + wx * (p11[c] - p10[c]);
+            const float p00 = (float)((t00 >> (8 * c)) & 255u), p01 = (float)((t01 >> (8 * c)) & 255u);
+            const float p10 = (float)((t10 >> (8 * c)) & 255u), p11 = (float)((t11 >> (8 * c)) & 255u);
+            const float top = p00 + wx * (p01 - p00);
+            const float bot = p10 + wx * (p11 - p10);
             const float v = top + wy * (bot - top);
             o[c][k] = f32_to_bf16(v * na[c] + nb[c]);
         }
     }
     if (miss && !is_template) s.window_miss = s.frames_done + 1;   // every writer stores the same value
-    const int grid = size / patch;
-    const int token = (oy / patch) * grid + (ox0 / patch);         // PX divides patch: one token per group
-    const int kin = (oy % patch) * patch + (ox0 % patch);
-    bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         uint4 v;
