@@ -45,6 +45,7 @@
 //
 // Epilogues go through LDS (dead after the loop) so that global stores are whole rows:
 // f32 outputs in two passes of 128 rows x 1 KiB, bf16 outputs in one pass of 256 rows x 512 B.
+#include <type_traits>
 #include "vt_common.hpp"
 #include "k_gemm_util.hpp"
 
@@ -454,19 +455,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int nchunk = p.N / VT_STAT_CHUNK;
         // row pair `it` (0..7) of pass i that this wave writes out: pass rows lr = it*16 + wave*2 + rsub
         auto out_row = [&](int i, int it) { const int lr = it * 16 + wave * 2 + rsub; return m0 + (lr >> 6) * 128 + i * 64 + (lr & 63); };
+        // Round 4: the epilogue issues ~2,700 instructions per wave and tile, two waves per SIMD, with the matrix
+        // pipe idle - its vector issue is half of its time. The pair and the chunk partials are addressed as a
+        // UNIFORM row-pair base (scalar ALU; the wave index through readfirstlane) + a 32-bit per-lane offset,
+        // which hipcc turns into the saddr form of global_load / global_store: no 64-bit vector address
+        // arithmetic. Whether a row pair lies inside M is a scalar test (both rows valid: plain stores, no
+        // exec-mask branch; M is even for every engine, so only row pairs entirely past M take the guarded path).
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t lane_off = (uint32_t)(rsub * p.ldx + n8) * 2u;                       // bytes inside the row pair
+        const uint32_t lane_off0 = (uint32_t)n8 * 2u;                                       // ... with the row clamped to the pair's first
+        const uint32_t lane_off_c = (uint32_t)(rsub * nchunk + (n8 / VT_STAT_CHUNK)) * 8u;   // float2 entries
+        auto row_u = [&](int i, int it) { return m0 + (it >> 2) * 128 + i * 64 + (it & 3) * 16 + wave_u * 2; };   // uniform
         auto load_addend = [&](int i, int it, u32x4_t& a0, u32x4_t& a1) {
-            const int m = out_row(i, it);
-            const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
             if constexpr (EPI == EPI_RESID) {
-                a0 = *reinterpret_cast<const u32x4_t*>(p.Xh + (size_t)mc * p.ldx + n8);
+                // rows past M read a valid row (value unused): the pair's base clamped on the scalar side, the
+                // second row folded onto the first where it alone is past M
+                const int mu = row_u(i, it), mc = mu < p.M ? mu : p.M - 1;
+                const size_t ro = (size_t)mc * p.ldx * 2;
+                const uint32_t lo_ = (mc + 1 < p.M) ? lane_off : lane_off0;
+                a0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xh) + ro + lo_);
 #ifdef VT_AB_NOLO    /* tuning builds only: upper bound of what cutting the pair's bytes can buy (wrong results) */
                 a1 = u32x4_t{0u, 0u, 0u, 0u};
 #elif defined(VT_AB_LO8)
-                { const uint2 t2 = *reinterpret_cast<const uint2*>(p.Xl + (size_t)mc * p.ldx + n8); a1 = u32x4_t{t2.x, t2.y, 0u, 0u}; }
+                { const uint2 t2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.Xl) + ro + lo_); a1 = u32x4_t{t2.x, t2.y, 0u, 0u}; }
 #else
-                a1 = *reinterpret_cast<const u32x4_t*>(p.Xl + (size_t)mc * p.ldx + n8);
+                a1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xl) + ro + lo_);
 #endif
             } else if constexpr (EPI == EPI_F32_POS) {
+                const int m = out_row(i, it);
+                const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
                 const float* src = p.pos + (size_t)(mc % p.pos_rows) * p.ldx + n8;
                 a0 = *reinterpret_cast<const u32x4_t*>(src);
                 a1 = *reinterpret_cast<const u32x4_t*>(src + 4);
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         auto write_pass = [&](int i, const u32x4_t (&ad)[8][2]) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int lr = it * 16 + wave * 2 + rsub, m = out_row(i, it);
+                const int lr = it * 16 + wave * 2 + rsub;
                 const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + (((2 * c8) ^ (lr & 7)) << 4));
                 const f32x4_t f1 = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + (((2 * c8 + 1) ^ (lr & 7)) << 4));
                 float add[8], x[8];
@@ -510,25 +527,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 x_chunk_stats(x, csum, cm2);
                 u32x4_t hi, lo;
                 x_split8(x, hi, lo);
-                if (m < p.M) {
-                    *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
+                // chunk partials: two chunks (this quad's and the next one's) per 16-B WRITE-THROUGH (sc1) store -
+                // the row panel's last workgroup may read them in this launch (finalize below); as 8-B sc1 stores
+                // they were 518 k single fabric writes per launch (an 8-B write-through store costs 2.7x a 16-B
+                // one per byte): + 5 us on fc2. The next quad's partials (lane + 4, same 16-lane row: the storing
+                // lanes sit at 0 and 8 of a row) come by DPP row_shl:4 - one vector move each instead of a
+                // ds_bpermute round trip through the LDS.
+                const float nsum = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, csum), 0x104, 0xF, 0xF, true));
+                const float nm2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cm2), 0x104, 0xF, 0xF, true));
+                const f32x4_t v4 = {csum, cm2, nsum, nm2};
+                const int mu = row_u(i, it);
+                const size_t ro = (size_t)mu * p.ldx * 2;
+                char* const dh = reinterpret_cast<char*>(p.Xh) + ro + lane_off;
+                char* const dl = reinterpret_cast<char*>(p.Xl) + ro + lane_off;
+                char* const dc = reinterpret_cast<char*>(p.cstat) + (size_t)mu * nchunk * 8 + lane_off_c;
+                const bool cst = p.cstat && (c8 & 7) == 0;
+                if (mu + 1 < p.M) {                 // scalar: both rows of the pair inside M
+                    *reinterpret_cast<u32x4_t*>(dh) = hi;
 #ifdef VT_AB_NOLO
                     asm volatile("" :: "v"(lo));
 #elif defined(VT_AB_LO8)   /* tuning builds only: an 8-byte store in place of the 16-byte one (timing of a 3-B format) */
-                    *reinterpret_cast<uint2*>(p.Xl + (size_t)m * p.ldx + n8) = make_uint2(lo[0], lo[1]);
+                    *reinterpret_cast<uint2*>(dl) = make_uint2(lo[0], lo[1]);
 #else
-                    *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
+                    *reinterpret_cast<u32x4_t*>(dl) = lo;
 #endif
-                }
-                // chunk partials: two chunks (this quad's and the next one's, fetched from lane + 4) per 16-B
-                // WRITE-THROUGH (sc1) store - the row panel's last workgroup may read them in this launch
-                // (finalize below). As 8-B sc1 stores they were 518 k single fabric writes per launch (an 8-B
-                // write-through store costs 2.7x a 16-B one per byte): + 5 us on fc2.
-                const float nsum = __shfl_down(csum, 4), nm2 = __shfl_down(cm2, 4);
-                if (m < p.M && p.cstat && (c8 & 7) == 0) {
-                    const f32x4_t v4 = {csum, cm2, nsum, nm2};
-                    float2* dst = p.cstat + (size_t)m * nchunk + (n8 / VT_STAT_CHUNK);
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v4) : "memory");
+                    if (cst) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dc), "v"(v4) : "memory");
+                } else if (mu + rsub < p.M) {       // the last row of an odd M
+                    *reinterpret_cast<u32x4_t*>(dh) = hi;
+                    *reinterpret_cast<u32x4_t*>(dl) = lo;
+                    if (cst) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dc), "v"(v4) : "memory");
                 }
             }
         };
