@@ -68,3 +68,27 @@ def test_bf16_oracle_stays_within_bf16_noise_of_the_unquantised_answer(vt, oracl
     r_t = 1 / (1 + np.exp(-truth["head_out"][:, 0])) * hann
     assert int(np.argmax(r_o)) == int(np.argmax(r_t))
     assert abs(r_o.max() - r_t.max()) < 0.02
+
+
+def test_float32_cpu_baseline_computes_the_same_tracker(vt, oracle, weights_cfg2):
+    """oracle/cpu_fp32.py - what bench.py's `cpu_baseline` times: float32 torch-CPU network, no bf16 rounding
+    emulation - against the bf16 oracle on the same 1080p clip (ViT-B/16 t128/s256), closed loop: same argmax cell,
+    identical integer boxes within a pixel, float boxes within 0.1 px (measured 0.01-0.02), scores within 0.01.
+    The timed baseline is the same tracker, not a lookalike."""
+    from oracle import cpu_fp32
+    w, h = 1920, 1080
+    sc = vt.synth.MovingSquare(w, h, 64, seed=3)
+    a, b = cpu_fp32.VitTrackFp32(weights_cfg2, threads=4), oracle.VitTrackRef(weights_cfg2)
+    worst = 0.0
+    for t in range(4):
+        f = oracle.Frame.nv12(sc.frame_nv12(t), w, h)
+        if t == 0:
+            a.init(f, sc.gt_box(0))
+            b.init(f, sc.gt_box(0))
+        ra, rb = a.update(f), b.update(f)
+        assert ra.idx == rb.idx and ra.success == rb.success
+        assert max(abs(x - y) for x, y in zip(ra.bbox, rb.bbox)) <= 1
+        worst = max(worst, float(abs(ra.fbox - rb.fbox).max()))
+        assert abs(ra.score - rb.score) < 0.01
+    assert worst < 0.1, worst
+    assert cpu_fp32.cpu_model_name()
