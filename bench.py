@@ -310,26 +310,41 @@ def run_rank(args):
                     ok = ok and all(x.success for x in r)
             return ok, r
 
+        errs = []
+
         def worker(gi):
-            if W_ > 0:
-                run(gi, 1, W_)
-            start.wait()
-            oks[gi], results[gi] = run(gi, W_ + 1, K_)
-            stop.wait()
+            try:
+                if W_ > 0:
+                    run(gi, 1, W_)
+                start.wait()
+                oks[gi], results[gi] = run(gi, W_ + 1, K_)
+                stop.wait()
+            except threading.BrokenBarrierError:
+                pass
+            except BaseException as e:          # a failing engine must not leave the other threads at a barrier
+                errs.append(e)
+                start.abort()
+                stop.abort()
 
         th = [threading.Thread(target=worker, args=(gi,)) for gi in range(G)]
         [x.start() for x in th]
         # the workers are in their warm-up; join them at the start line, then open the timed region
-        while start.n_waiting < G:
+        while start.n_waiting < G and not errs:
             time.sleep(0.0005)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        start.wait()
-        stop.wait()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
+        try:
+            if errs:
+                raise errs[0]
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            start.wait()
+            stop.wait()
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            [x.join() for x in th]
+            raise errs[0] if errs else RuntimeError("host ingest worker failed")
         [x.join() for x in th]
         res = [r for g in range(G) for r in results[g]]
         ok, miou = check_tracking(res, W_ + K_, W_ + K_)
