@@ -1,6 +1,10 @@
 #!/bin/bash
 # round-4 experiments, one GPU session: (1) fc1 tile order / A-operand cache policy (time, alternating builds in one
 # process, then fabric reads and L2 hit rate per build), (2) what cutting the residual pair's bytes buys the X-epilogues
+# builds first (in the container; the .so files travel with the snapshot):
+#   cd gstreamer-vit-tracker_amd && for v in "own -DVT_AB_OWN" "ownnt -DVT_AB_OWN -DVT_AB_ANT" "ant -DVT_AB_ANT" "nolo -DVT_AB_NOLO" "lo8 -DVT_AB_LO8"; do
+#       set -- $v; n=$1; shift; python build.py --variant $n "$@"; done
+# (round 4's base build for this script had plain output stores: add -DVT_AB_PLAINOUT to reproduce its "base")
 set -u
 P=gstreamer-vit-tracker_amd
 OUT=gpurun_out/r4_exp1

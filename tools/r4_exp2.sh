@@ -1,6 +1,8 @@
 #!/bin/bash
 # round-4 experiment 2: write-through (sc1) output stores in the persistent GEMM, with and without XCD ownership
 set -u
+# builds first: python build.py --variant base -DVT_AB_PLAINOUT; --variant own -DVT_AB_OWN -DVT_AB_PLAINOUT; --variant sc1 (today's default);
+#               --variant ownsc1 -DVT_AB_OWN   (when this script ran, write-through stores were the flag -DVT_AB_SC1OUT and plain stores the default)
 P=gstreamer-vit-tracker_amd
 OUT=gpurun_out/r4_exp2
 mkdir -p $OUT
