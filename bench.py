@@ -568,10 +568,19 @@ def run_rank(args):
         ntrk = 300
         trk = vt.VitTrack(wpath)
         single = {}
-        for name in ("host_pointer", "device_pointer"):
+        hm1 = None
+        for name in ("host_pointer", "host_pointer_registered", "device_pointer"):
             if name == "host_pointer":
                 trk.init(hclip[0], vt.BBox.new(*sc.gt_box(0)))
                 call = lambda t: trk.update(hclip[t % R])
+            elif name == "host_pointer_registered":
+                # the same host-pointer calls on frames inside a range registered with vt_host_register: the library
+                # takes the zero-copy route by itself (no window packing, no staging copy)
+                reg = np.array(host)
+                hm1 = vt.HostMapping(reg)
+                rclip = [vt.NV12Frame(reg[t], fw, fh) for t in range(R)]
+                trk.init(rclip[0], vt.BBox.new(*sc.gt_box(0)))
+                call = lambda t: trk.update(rclip[t % R])
             else:
                 trk.init_nv12_device(base, base + fw * fh, fw, fh, fw, fw, vt.BBox.new(*sc.gt_box(0)))
                 call = lambda t: trk.update_nv12_device(base + (t % R) * fbytes, base + (t % R) * fbytes + fw * fh, fw, fh, fw, fw)
@@ -596,6 +605,8 @@ def run_rank(args):
                              for p in sorted(prof1, key=lambda p: -p["ms"])]
         out["single_stream"] = single
         del trk
+        if hm1 is not None:
+            hm1.close()
 
     # ---- byte-bound kernels against the HBM roofline (north_star: "HBM GB/s against gfx950 peak") ------
     if not args.no_profile and rank == 0:

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -935,6 +937,21 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
     return VT_OK;
 } VT_NOTHROW_INT
 
+// Host ranges mapped by vt_host_register: the host-pointer entry points look a frame's planes up here and, when
+// both lie in a mapped range of the engine's device, hand the kernels the mapped pointers (no window packing, no
+// staging copy). A handful of entries; a mutex, because registration and tracking run on different threads.
+struct HostRange { const uint8_t* host; size_t bytes; uint8_t* dev; int device; };
+static std::mutex g_ranges_mu;
+static std::vector<HostRange> g_ranges;
+static std::atomic<int> g_ranges_n{0};
+static const uint8_t* mapped_device_ptr(int device, const uint8_t* p) {
+    if (!p || g_ranges_n.load(std::memory_order_acquire) == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (const HostRange& r : g_ranges)
+        if (r.device == device && p >= r.host && p < r.host + r.bytes) return r.dev + (p - r.host);
+    return nullptr;
+}
+
 int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr) try {
     if (!host_ptr || !d_ptr || bytes == 0) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     *d_ptr = nullptr;
@@ -949,6 +966,11 @@ int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr) 
         return set_err(VT_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(he));
     }
     *d_ptr = dp;
+    {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        g_ranges.push_back(HostRange{(const uint8_t*)host_ptr, bytes, (uint8_t*)dp, device_id});
+        g_ranges_n.store((int)g_ranges.size(), std::memory_order_release);
+    }
     return VT_OK;
 } VT_NOTHROW_INT
 
@@ -956,6 +978,15 @@ int vt_host_unregister(int device_id, void* host_ptr) try {
     if (!host_ptr) return set_err(VT_ERR_INVALID_ARG, "null pointer");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
+    {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        for (size_t i = 0; i < g_ranges.size(); ++i)
+            if (g_ranges[i].host == (const uint8_t*)host_ptr && g_ranges[i].device == device_id) {
+                g_ranges.erase(g_ranges.begin() + (long)i);
+                break;
+            }
+        g_ranges_n.store((int)g_ranges.size(), std::memory_order_release);
+    }
     (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
     hipError_t he = hipHostUnregister(host_ptr);
     if (he != hipSuccess) return set_err(VT_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(he));
@@ -1399,18 +1430,32 @@ static void pack_window(const Arena& a, const HostWin& wn, size_t off, vt_frame*
 static int stage_host_frames_to(Engine* e, const Arena& a, const vt_frame* host, int n, const float (*boxes)[4],
                                 float grow, vt_frame* dev, size_t* bytes_out) {
     std::vector<HostWin> wins((size_t)n);
+    std::vector<char> mapped((size_t)n, 0);
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         const vt_frame& hf = host[i];
         if (int rc = plan_window(e, hf.format, (const uint8_t*)hf.plane0, (const uint8_t*)hf.plane1, hf.width,
                                  hf.height, hf.stride0, hf.stride1, boxes[i], grow, &wins[i]))
             return rc;
+        // a frame inside a range mapped by vt_host_register goes to the kernels as it lies (zero copy)
+        const uint8_t* d0 = mapped_device_ptr(e->device, (const uint8_t*)hf.plane0);
+        const uint8_t* d1 = hf.format == VT_PIX_NV12 ? mapped_device_ptr(e->device, (const uint8_t*)hf.plane1) : nullptr;
+        if (d0 && (hf.format != VT_PIX_NV12 || d1)) {
+            mapped[(size_t)i] = 1;
+            memset(&dev[i], 0, sizeof(vt_frame));
+            dev[i].plane0 = d0; dev[i].plane1 = d1; dev[i].width = hf.width; dev[i].height = hf.height;
+            dev[i].stride0 = hf.stride0; dev[i].stride1 = hf.stride1; dev[i].format = hf.format;
+            continue;
+        }
         total += wins[i].bytes;
     }
+    if (bytes_out) *bytes_out = total;
+    if (total == 0) return VT_OK;            // every frame mapped: nothing to pack, nothing to copy
     if (int rc = ensure_arena(e, a, total)) return rc;
     DEVICE_SCOPE(e->device);
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
+        if (mapped[(size_t)i]) continue;
         pack_window(a, wins[i], off, &dev[i]);
         off += wins[i].bytes;
     }

@@ -271,8 +271,10 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
  * (typically the capture pool, once at start-up) and maps it into the device's address space
  * (hipHostRegister + hipHostGetDevicePointer): *d_ptr + offset may then be used as plane0 / plane1 of a
  * vt_frame with the *_device entry points, and the pixel kernel reads only the pixels it samples over
- * PCIe - no staging copy, no packing on the CPU, whatever the frame size. The memory stays owned by the
- * caller; unregister before freeing it. */
+ * PCIe - no staging copy, no packing on the CPU, whatever the frame size. The HOST-pointer entry points
+ * (vt_init_* / vt_update_* and vt_group_*_host) recognise a frame whose planes lie inside a registered range of
+ * their device and take the same zero-copy route by themselves: a host that registers its capture pool once keeps
+ * calling update(host pointer) as before. The memory stays owned by the caller; unregister before freeing it. */
 int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr);
 int vt_host_unregister(int device_id, void* host_ptr);
 

@@ -735,3 +735,45 @@ def test_zero_copy_host_mapping_tracks_like_device_frames(gpu, oracle, weights_t
         hm.close()
     with pytest.raises(gpu.VtError):
         gpu.HostMapping(np.zeros(0, np.uint8))
+
+
+def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, weights_tiny):
+    """a host that registered its capture pool keeps calling update(host pointer): frames inside a registered
+    range skip window packing and the staging copy (vt_host_register). Results are those of the same calls on
+    unregistered memory, bit for bit - single tracker, group synchronous and group pipelined - and after
+    vt_host_unregister the same buffers go through the staging path again."""
+    w, h, n, B = 640, 480, 8, 2
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=23)
+    clip = np.stack([sc.frame_nv12(t) for t in range(n)])          # to be registered
+    plain = clip.copy()                                             # never registered
+
+    def run_single(buf):
+        trk = gpu.VitTrack.new(weights_tiny)
+        trk.init(gpu.NV12Frame(buf[0], w, h), gpu.BBox.new(*sc.gt_box(0)))
+        return [(r.bbox, r.score, r.success) for r in (trk.update(gpu.NV12Frame(buf[t], w, h)) for t in range(n))]
+
+    def run_group(buf, pipelined):
+        g = gpu.Group(weights_tiny, n_streams=B)
+        for i in range(B):
+            g.init_host(i, gpu.NV12Frame(buf[0], w, h), gpu.BBox.new(*sc.gt_box(0)))
+        out = []
+        if pipelined:
+            g.enqueue_host([gpu.NV12Frame(buf[1], w, h)] * B)
+            for t in range(2, n):
+                g.enqueue_host([gpu.NV12Frame(buf[t], w, h)] * B)
+                out.append([(r.bbox, r.score) for r in g.wait_next()])
+            out.append([(r.bbox, r.score) for r in g.wait_next()])
+            assert g.host_redos() == 0 or buf is plain     # whole mapped frames cannot miss their window
+        else:
+            for t in range(1, n):
+                out.append([(r.bbox, r.score) for r in g.update_host([gpu.NV12Frame(buf[t], w, h)] * B)])
+        return out
+
+    want = (run_single(plain), run_group(plain, False), run_group(plain, True))
+    hm = gpu.HostMapping(clip)
+    try:
+        got = (run_single(clip), run_group(clip, False), run_group(clip, True))
+    finally:
+        hm.close()
+    assert got == want
+    assert run_single(clip) == want[0]                      # unregistered again: the staging path
