@@ -944,11 +944,13 @@ struct HostRange { const uint8_t* host; size_t bytes; uint8_t* dev; int device; 
 static std::mutex g_ranges_mu;
 static std::vector<HostRange> g_ranges;
 static std::atomic<int> g_ranges_n{0};
-static const uint8_t* mapped_device_ptr(int device, const uint8_t* p) {
-    if (!p || g_ranges_n.load(std::memory_order_acquire) == 0) return nullptr;
+// the whole extent [p, p + bytes) must lie inside one mapped range: a frame that only starts in one is staged
+static const uint8_t* mapped_device_ptr(int device, const uint8_t* p, size_t bytes) {
+    if (!p || bytes == 0 || g_ranges_n.load(std::memory_order_acquire) == 0) return nullptr;
     std::lock_guard<std::mutex> lk(g_ranges_mu);
     for (const HostRange& r : g_ranges)
-        if (r.device == device && p >= r.host && p < r.host + r.bytes) return r.dev + (p - r.host);
+        if (r.device == device && p >= r.host && p < r.host + r.bytes && bytes <= (size_t)(r.host + r.bytes - p))
+            return r.dev + (p - r.host);
     return nullptr;
 }
 
@@ -1438,8 +1440,12 @@ static int stage_host_frames_to(Engine* e, const Arena& a, const vt_frame* host,
                                  hf.height, hf.stride0, hf.stride1, boxes[i], grow, &wins[i]))
             return rc;
         // a frame inside a range mapped by vt_host_register goes to the kernels as it lies (zero copy)
-        const uint8_t* d0 = mapped_device_ptr(e->device, (const uint8_t*)hf.plane0);
-        const uint8_t* d1 = hf.format == VT_PIX_NV12 ? mapped_device_ptr(e->device, (const uint8_t*)hf.plane1) : nullptr;
+        // bytes the kernels may touch: every row of the frame, the last one only as far as it is wide
+        const size_t rowb = hf.format == VT_PIX_NV12 ? (size_t)hf.width : hf.format == VT_PIX_RGB8 ? (size_t)hf.width * 3 : (size_t)hf.width * 2;
+        const size_t ext0 = (size_t)(hf.height - 1) * (size_t)hf.stride0 + rowb;
+        const size_t ext1 = hf.format == VT_PIX_NV12 ? (size_t)((hf.height + 1) / 2 - 1) * (size_t)hf.stride1 + (size_t)((hf.width + 1) & ~1) : 0;
+        const uint8_t* d0 = mapped_device_ptr(e->device, (const uint8_t*)hf.plane0, ext0);
+        const uint8_t* d1 = hf.format == VT_PIX_NV12 ? mapped_device_ptr(e->device, (const uint8_t*)hf.plane1, ext1) : nullptr;
         if (d0 && (hf.format != VT_PIX_NV12 || d1)) {
             mapped[(size_t)i] = 1;
             memset(&dev[i], 0, sizeof(vt_frame));

@@ -777,3 +777,17 @@ def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, 
         hm.close()
     assert got == want
     assert run_single(clip) == want[0]                      # unregistered again: the staging path
+    # a frame that only STARTS inside a registered range (its tail lies in unregistered memory) must be staged,
+    # not read through the mapping: register all but the last 4 KiB of a buffer that holds one frame at its end
+    fb = clip.shape[1]
+    big = np.zeros(fb + 8192, np.uint8)
+    big[8192:] = clip[0]
+    part = gpu.HostMapping(big[: fb + 8192 - 4096])
+    try:
+        trk = gpu.VitTrack.new(weights_tiny)
+        f = gpu.NV12Frame(big[8192:], w, h)
+        trk.init(f, gpu.BBox.new(*sc.gt_box(0)))
+        r = trk.update(f)
+        assert (r.bbox, r.score, r.success) == want[0][0]
+    finally:
+        part.close()
