@@ -181,3 +181,32 @@ def test_oracle_parser_is_independent_and_agrees_with_the_writer(vt):
         assert t1[k].dtype == t2[k].dtype and np.array_equal(t1[k], t2[k]), k
     with pytest.raises(ValueError):
         vit_ref.parse_vtwb(b"NOTAVTWB" + raw[8:])
+
+
+def test_make_traj_fbox_mode_reproduces_the_fixture_and_appends_float_boxes(vt, oracle, weights_tiny, tmp_path, monkeypatch):
+    """tests/golden/make_traj.py: `traj` writes a closed-loop oracle trajectory, `fbox` re-evaluates every frame of
+    an existing fixture from its recorded state, insists on reproducing the stored integer boxes / scores / cells
+    exactly, and appends the float boxes the teacher-forced GPU tests assert on. Here on the tiny model."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_traj", os.path.join(root, "tests", "golden", "make_traj.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    monkeypatch.setattr(mt, "HERE", str(tmp_path))
+    out = str(tmp_path / "traj_tiny_6.npz")
+    mt.run("tiny", weights_tiny, 6, 4, out, verbose=False)
+    with np.load(out) as z:
+        a = {k: z[k] for k in z.files}
+    assert a["fbox"].shape == (6, 4) and np.abs(a["fbox"][:, :2] - a["bbox"][:, :2]).max() <= 0.5 + 1e-3
+    # strip fbox, let the tool put it back: identical values
+    b = {k: v for k, v in a.items() if k != "fbox"}
+    np.savez_compressed(out, **b)
+    mt.add_fbox("traj_tiny_6.npz")
+    with np.load(out) as z:
+        assert np.array_equal(z["fbox"], a["fbox"]) and np.array_equal(z["bbox"], a["bbox"])
+    # a fixture whose stored box no longer matches what the oracle computes is refused
+    b["bbox"] = b["bbox"].copy()
+    b["bbox"][3, 0] += 1
+    np.savez_compressed(out, **b)
+    with pytest.raises(AssertionError):
+        mt.add_fbox("traj_tiny_6.npz")
