@@ -85,7 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="independent tracked streams per GPU (0: groups x weights.recommended_streams)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent tracked streams per GPU (0: groups x weights.recommended_streams). "
+                         "BASELINE.json configs[3] taken literally (8 independent streams, ONE per GPU) is "
+                         "`--gpus 8 --streams 1 --groups 1`; the line then carries config.cfg4_literal = true. The "
+                         "default keeps 60 streams per GPU (weak scaling of the batched engines)")
     ap.add_argument("--groups", type=int, default=2,
                     help="engines per GPU, each with streams/groups streams on its own HIP stream "
                          "(kernels of different groups overlap on the chip)")
@@ -149,6 +153,10 @@ def main(argv=None):
 
 
 def run_rank(args):
+    # dmabuf IPC only on this pool: RCCL's (and torch's) cross-process buffer sharing fails with
+    # hipIpcGetMemHandle otherwise. Set before torch / HIP load, so that ranks started by an external
+    # `python -m torch.distributed.run ... bench.py --gpus N` get it exactly like the self-launched ones.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import gstreamer_vit_tracker_amd as vt
@@ -372,6 +380,7 @@ def run_rank(args):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": wl_text, "vit_config": cfg_name, "frame": f"{fw}x{fh} NV12",
                    "streams_per_gpu": B, "engines_per_gpu": G, "engine_sizes": sizes, "tokens": mi.tokens_template + mi.tokens_search,
+                   "cfg4_literal": bool(B == 1 and G == 1),     # BASELINE.json configs[3]: one stream per GPU
                    "ingest": ingest_text, "launch": "eager" if args.eager else "hipGraph",
                    "weights": "synthetic seeded encoder + fitted head (no reference weights exist)"},
         "per_stream_fps": fps / (world * B),
@@ -700,6 +709,7 @@ def dry_run(args, vt, vd, world, rank, cfg_name, wl_text):
             "data": "none (dry run: synthetic timings, no kernels ran)",
             "config": {"workload": wl_text, "vit_config": cfg_name, "streams_per_gpu": B},
             "per_rank_fps": per_rank, "collective": collective,
+            "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             "global_stream_ids_rank0": plan["global_stream_ids"]}))
     if world > 1:
         dist.destroy_process_group()

@@ -56,7 +56,8 @@ pub struct VtConfig {
     pub max_frame_height: i32,
     pub max_device_mib: i32,
     pub host_window_margin_pct: i32,
-    pub reserved: [i32; 6],
+    pub host_zero_copy: i32,
+    pub reserved: [i32; 5],
 }
 
 /// ≙ vt_model_info

@@ -42,7 +42,7 @@ class CConfig(Structure):
     _fields_ = [("struct_size", c_uint32), ("success_threshold", c_float), ("use_graph", c_int32),
                 ("n_streams", c_int32), ("max_frame_width", c_int32),
                 ("max_frame_height", c_int32), ("max_device_mib", c_int32),
-                ("host_window_margin_pct", c_int32), ("reserved", c_int32 * 6)]
+                ("host_window_margin_pct", c_int32), ("host_zero_copy", c_int32), ("reserved", c_int32 * 5)]
 
 
 class CModelInfo(Structure):
@@ -308,7 +308,7 @@ def _f32(a):
 
 
 def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, max_h=0,
-                max_device_mib=0, host_window_margin_pct=0) -> CConfig:
+                max_device_mib=0, host_window_margin_pct=0, host_zero_copy=0) -> CConfig:
     c = CConfig()
     lib().vt_config_default(byref(c))
     c.success_threshold = success_threshold
@@ -317,6 +317,7 @@ def make_config(success_threshold=-1.0, use_graph=True, n_streams=1, max_w=0, ma
     c.max_frame_width, c.max_frame_height = max_w, max_h
     c.max_device_mib = max_device_mib
     c.host_window_margin_pct = host_window_margin_pct
+    c.host_zero_copy = host_zero_copy
     return c
 
 
@@ -478,12 +479,12 @@ class Group:
     def __init__(self, weights_path: str | None = None, n_streams: int = 1, device: int = 0,
                  success_threshold: float = -1.0, use_graph: bool = True,
                  device_blob: tuple[int, int] | None = None, max_device_mib: int = 0,
-                 host_window_margin_pct: int = 0):
+                 host_window_margin_pct: int = 0, host_zero_copy: int = 0):
         self._h = c_void_p()
         self._owner = None
         self._keep = {}
         cfg = make_config(success_threshold, use_graph, n_streams, max_device_mib=max_device_mib,
-                          host_window_margin_pct=host_window_margin_pct)
+                          host_window_margin_pct=host_window_margin_pct, host_zero_copy=host_zero_copy)
         if device_blob is not None:
             ptr, nbytes = device_blob
             _check(lib().vt_group_create_from_device_blob(ptr, nbytes, device, byref(cfg),

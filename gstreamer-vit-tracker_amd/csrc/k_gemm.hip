@@ -568,7 +568,7 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     X(4, 64, 64, 2, 2, 3, 128, EPI)   \
     X(5, 64, 64, 2, 2, 2, 128, EPI)   \
     X(6, 128, 128, 2, 2, 2, 128, EPI)
-#define GEMM_NUM_CFG 20   // valid: 0..6 (this file), 16 (k_gemm128.hip) and 17, 18, 19 (k_gemm256.hip)
+#define GEMM_NUM_CFG 20   // valid: 0..6 (this file) and 17, 18, 19 (k_gemm256.hip)
 
 template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
 static hipError_t prepare_cfg() {
@@ -597,7 +597,6 @@ hipError_t gemm_prepare() {
     if ((e = prepare_epi<EPI_RELU_BF16>()) != hipSuccess) return e;
     if ((e = prepare_epi<EPI_QKV>()) != hipSuccess) return e;
     if ((e = prepare_epi<EPI_F32>()) != hipSuccess) return e;
-    if ((e = gemm128_prepare()) != hipSuccess) return e;
     return gemm256_prepare();
 }
 
@@ -696,7 +695,6 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
         return hipErrorInvalidValue;
     if (!x_epi && (!a.bias || ((a.rowstat || a.cstat_in) && !a.colsum))) return hipErrorInvalidValue;
     if (a.cstat_in && (cfg > 6 || a.rowstat || (a.K % (4 * VT_STAT_CHUNK)) != 0 || a.K > 1024)) return hipErrorInvalidValue;
-    if (cfg == GEMM_CFG_128X256) return launch_gemm128(a, epilogue, st);
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
     if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
     if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);

@@ -113,7 +113,6 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv = false);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
 // k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
-#define GEMM_CFG_128X256 16    // 128x256 tiles, 4 waves, two workgroups per CU (k_gemm128.hip)
 #define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
 #define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
 #define GEMM_CFG_256PP 19      // v2, persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)
@@ -122,9 +121,6 @@ hipError_t gemm_prepare();  // once per device, before the first launch / any st
 hipError_t gemm256_prepare();
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st);
 bool gemm256_fits(const GemmArgs& a, int epilogue);
-hipError_t gemm128_prepare();
-hipError_t launch_gemm128(const GemmArgs& a, int epilogue, hipStream_t st);
-bool gemm128_fits(const GemmArgs& a, int epilogue);
 // the tile configuration launch_gemm() runs for these arguments (the picker's choice, or the 4-wave
 // kernel where a 256x256 choice does not fit the operands)
 int gemm_effective_config(const GemmArgs& a, int epilogue);

@@ -184,6 +184,7 @@ struct Engine {
     unsigned host_seq = 0, host_collected = 0;   // pipelined passes enqueued / collected
     unsigned host_redos = 0;                      // passes redone because a speculative window missed
     float margin = 0.75f;                         // speculative enlargement of the crop side
+    int host_zero_copy = 0;                       // vt_config.host_zero_copy: 0 auto (single-stream engines), 1 always, -1 never
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
 
@@ -823,6 +824,7 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
             if (cfg->max_device_mib > 0) e->max_device_bytes = (size_t)cfg->max_device_mib << 20;
             if (cfg->host_window_margin_pct > 0) e->margin = std::min(cfg->host_window_margin_pct, 400) / 100.0f;
             else if (cfg->host_window_margin_pct < 0) e->margin = 0.0f;
+            e->host_zero_copy = cfg->host_zero_copy;
         }
         if ((rc = e->alloc_buffers())) break;
     } while (0);
@@ -1439,7 +1441,11 @@ static int stage_host_frames_to(Engine* e, const Arena& a, const vt_frame* host,
         if (int rc = plan_window(e, hf.format, (const uint8_t*)hf.plane0, (const uint8_t*)hf.plane1, hf.width,
                                  hf.height, hf.stride0, hf.stride1, boxes[i], grow, &wins[i]))
             return rc;
-        // a frame inside a range mapped by vt_host_register goes to the kernels as it lies (zero copy)
+        // a frame inside a range mapped by vt_host_register goes to the kernels as it lies (zero copy) - on
+        // single-stream engines, or where the caller asked for it: for a batched engine the packed upload beside
+        // the previous pass is faster than PCIe reads inside the pass (vt_config.host_zero_copy, vittrack_hip.h)
+        const bool zc = e->host_zero_copy > 0 || (e->host_zero_copy == 0 && e->B == 1);
+        if (!zc) { total += wins[i].bytes; continue; }
         // bytes the kernels may touch: every row of the frame, the last one only as far as it is wide
         const size_t rowb = hf.format == VT_PIX_NV12 ? (size_t)hf.width : hf.format == VT_PIX_RGB8 ? (size_t)hf.width * 3 : (size_t)hf.width * 2;
         const size_t ext0 = (size_t)(hf.height - 1) * (size_t)hf.stride0 + rowb;

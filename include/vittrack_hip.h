@@ -81,7 +81,11 @@ typedef struct vt_config {
     int32_t host_window_margin_pct; /* vt_group_enqueue_host: enlargement of the speculative window in
                                 * percent of the crop side; 0 -> 75 (see there); < 0 -> none (tests:
                                 * every moving target then takes the redo path) */
-    int32_t reserved[6];
+    int32_t host_zero_copy;    /* host-pointer calls on frames inside a vt_host_register range: 0 (default) =
+                                * zero-copy route on single-stream engines (vt_create, n_streams 1) only,
+                                * batched engines keep packing windows; 1 = zero-copy on every engine;
+                                * -1 = never (always pack + copy). Measured trade-off at vt_host_register */
+    int32_t reserved[5];
 } vt_config;
 #define VT_MAX_STREAMS 1024
 
@@ -273,8 +277,15 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
  * vt_frame with the *_device entry points, and the pixel kernel reads only the pixels it samples over
  * PCIe - no staging copy, no packing on the CPU, whatever the frame size. The HOST-pointer entry points
  * (vt_init_* / vt_update_* and vt_group_*_host) recognise a frame whose planes lie inside a registered range of
- * their device and take the same zero-copy route by themselves: a host that registers its capture pool once keeps
- * calling update(host pointer) as before. The memory stays owned by the caller; unregister before freeing it. */
+ * their device and MAY take the same zero-copy route by themselves (vt_config.host_zero_copy):
+ *   - single-stream engines (the reference's one tracker per process) do by default: + 1 % (1,250 -> 1,264
+ *     updates/s at cfg3, 1080p), and no CPU work per frame;
+ *   - batched engines do NOT by default: for them the packed-window upload is faster - 60 streams in two engines,
+ *     cfg3: pipelined vt_group_enqueue_host 6,891 frames/s, synchronous vt_group_update_host 6,721, zero copy 6,369
+ *     (profiles/r04_bench_cfg3_60x2_final.json) - the pixel kernel's PCIe reads are latency inside the pass, the
+ *     packed upload runs beside the previous pass. host_zero_copy = 1 opts a batched engine in (a host that cannot
+ *     spare the CPU time for packing: 92 % of the headline rate with no per-frame CPU work), -1 opts everything out.
+ * The memory stays owned by the caller; unregister before freeing it. */
 int vt_host_register(int device_id, void* host_ptr, size_t bytes, void** d_ptr);
 int vt_host_unregister(int device_id, void* host_ptr);
 

@@ -88,6 +88,29 @@ def test_bench_self_launches_its_ranks_gloo_dry_run(vt, weights_tiny):
     # rank r "took" 0.5 + r/4 s for 3 streams x 10 steps: whole job = 60 frames / 0.75 s
     assert d["per_rank_fps"] == pytest.approx([60.0, 40.0]) and d["value"] == pytest.approx(80.0)
     assert d["global_stream_ids_rank0"] == [0, 1, 2]
+    assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_externally_launched_ranks_set_the_ipc_mode_themselves(vt, weights_tiny):
+    """the driver's route: `python -m torch.distributed.run ... bench.py --gpus N` with the variable absent from
+    the environment - run_rank sets HSA_ENABLE_IPC_MODE_LEGACY=0 before torch / HIP load (dmabuf IPC is the only
+    mode this pool's driver supports; RCCL fails with hipIpcGetMemHandle otherwise), and the line records it"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "tiny", "--streams", "1",
+                        "--groups", "1", "--dry-run"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["collective"]["world_size"] == 2
+    assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_bench_launcher_does_not_touch_torch_in_the_parent_and_propagates_failure(vt):

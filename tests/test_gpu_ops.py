@@ -56,24 +56,6 @@ def test_gemm_every_tile_config(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("M,N,K,epi,ln", [(757, 768, 384, 2, False), (757, 768, 384, 3, False), (1000, 576, 768, 2, True),
-                                          (128, 192, 64, 3, False), (130, 960, 3072, 2, True), (21600 + 5, 192, 192, 2, True)])
-def test_gemm128_two_workgroups_per_cu_matches_the_256_kernel_bit_for_bit(gpu, M, N, K, epi, ln):
-    """config 16 (k_gemm128.hip: 128x192 tiles, 4 waves, two workgroups per CU): every output element is
-    one MFMA chain over K in the same order as in the other kernels, so the bf16 results are identical -
-    ragged last row panel, folded LayerNorm terms, a single K-step and a one-tile-wide N included"""
-    rng = np.random.default_rng(M + N + K)
-    ab, _ = _rand_bf16(gpu, rng, (M, K))
-    wb, _ = _rand_bf16(gpu, rng, (N, K), 0.05)
-    bias = rng.standard_normal(N).astype(np.float32)
-    kw = {}
-    if ln:
-        kw = dict(rowstat=np.stack([rng.uniform(0.5, 2, M), rng.standard_normal(M)], 1).astype(np.float32),
-                  colsum=rng.standard_normal(N).astype(np.float32))
-    ref = gpu.op_gemm_bf16(ab, wb, bias, epilogue=epi, cfg=2, **kw)          # 64x64 tiles: any N % 64 == 0
-    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=epi, cfg=16, **kw), ref)
-
-
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
 def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)

@@ -740,8 +740,10 @@ def test_zero_copy_host_mapping_tracks_like_device_frames(gpu, oracle, weights_t
 def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, weights_tiny):
     """a host that registered its capture pool keeps calling update(host pointer): frames inside a registered
     range skip window packing and the staging copy (vt_host_register). Results are those of the same calls on
-    unregistered memory, bit for bit - single tracker, group synchronous and group pipelined - and after
-    vt_host_unregister the same buffers go through the staging path again."""
+    unregistered memory, bit for bit - single tracker (the automatic route), group synchronous and group pipelined
+    (opted in with vt_config.host_zero_copy = 1; by default a batched engine keeps packing windows, which is faster
+    for it: vittrack_hip.h at vt_host_register) - and after vt_host_unregister the same buffers go through the
+    staging path again."""
     w, h, n, B = 640, 480, 8, 2
     sc = gpu.synth.MovingSquare(w, h, 64, seed=23)
     clip = np.stack([sc.frame_nv12(t) for t in range(n)])          # to be registered
@@ -752,8 +754,8 @@ def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, 
         trk.init(gpu.NV12Frame(buf[0], w, h), gpu.BBox.new(*sc.gt_box(0)))
         return [(r.bbox, r.score, r.success) for r in (trk.update(gpu.NV12Frame(buf[t], w, h)) for t in range(n))]
 
-    def run_group(buf, pipelined):
-        g = gpu.Group(weights_tiny, n_streams=B)
+    def run_group(buf, pipelined, zc=0):
+        g = gpu.Group(weights_tiny, n_streams=B, host_zero_copy=zc)
         for i in range(B):
             g.init_host(i, gpu.NV12Frame(buf[0], w, h), gpu.BBox.new(*sc.gt_box(0)))
         out = []
@@ -763,7 +765,7 @@ def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, 
                 g.enqueue_host([gpu.NV12Frame(buf[t], w, h)] * B)
                 out.append([(r.bbox, r.score) for r in g.wait_next()])
             out.append([(r.bbox, r.score) for r in g.wait_next()])
-            assert g.host_redos() == 0 or buf is plain     # whole mapped frames cannot miss their window
+            assert g.host_redos() == 0 or zc <= 0          # whole mapped frames cannot miss their window
         else:
             for t in range(1, n):
                 out.append([(r.bbox, r.score) for r in g.update_host([gpu.NV12Frame(buf[t], w, h)] * B)])
@@ -772,10 +774,13 @@ def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, 
     want = (run_single(plain), run_group(plain, False), run_group(plain, True))
     hm = gpu.HostMapping(clip)
     try:
-        got = (run_single(clip), run_group(clip, False), run_group(clip, True))
+        got = (run_single(clip), run_group(clip, False, 1), run_group(clip, True, 1))
+        dflt = (run_group(clip, False), run_group(clip, True))          # batched engines: packed windows by default
+        never = run_group(clip, True, -1)
     finally:
         hm.close()
     assert got == want
+    assert dflt == want[1:] and never == want[2]
     assert run_single(clip) == want[0]                      # unregistered again: the staging path
     # a frame that only STARTS inside a registered range (its tail lies in unregistered memory) must be staged,
     # not read through the mapping: register all but the last 4 KiB of a buffer that holds one frame at its end
@@ -791,3 +796,58 @@ def test_host_pointer_calls_take_the_zero_copy_route_for_registered_frames(gpu, 
         assert (r.bbox, r.score, r.success) == want[0][0]
     finally:
         part.close()
+
+
+def test_zero_copy_sees_a_registered_buffer_rewritten_in_place(gpu, weights_tiny):
+    """a capture pool recycles its buffers: the CPU rewrites the SAME registered buffer with frame t before every
+    update. The pixel kernel must see the new bytes each time (hipHostRegister's mapping is coherent: nothing of
+    an earlier frame may be served from a GPU cache) - single tracker (automatic zero-copy route), a group
+    synchronous and a group pipelined with two alternating registered buffers (host_zero_copy = 1; a pipelined
+    caller may not touch a buffer again before wait_next has returned its pass). Bit-identical to the staged path
+    on unregistered memory."""
+    w, h, n, B = 640, 480, 10, 2
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=29)
+    clip = np.stack([sc.frame_nv12(t) for t in range(n)])
+    fb = clip.shape[1]
+
+    def run_single(frame_of):
+        trk = gpu.VitTrack.new(weights_tiny)
+        trk.init(frame_of(0), gpu.BBox.new(*sc.gt_box(0)))
+        return [(r.bbox, r.score, r.success) for r in (trk.update(frame_of(t)) for t in range(n))]
+
+    def run_sync(frame_of, zc):
+        g = gpu.Group(weights_tiny, n_streams=B, host_zero_copy=zc)
+        f0 = frame_of(0)
+        for i in range(B):
+            g.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+        return [[(r.bbox, r.score) for r in g.update_host([frame_of(t)] * B)] for t in range(1, n)]
+
+    def run_pipe(frame_of, zc):
+        g = gpu.Group(weights_tiny, n_streams=B, host_zero_copy=zc)
+        f0 = frame_of(0)
+        for i in range(B):
+            g.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+        out = []
+        g.enqueue_host([frame_of(1)] * B)
+        for t in range(2, n):
+            g.enqueue_host([frame_of(t)] * B)      # buffer t & 1: the pass that read it (t - 2) has been waited for
+            out.append([(r.bbox, r.score) for r in g.wait_next()])
+        out.append([(r.bbox, r.score) for r in g.wait_next()])
+        return out
+
+    plain = lambda t: gpu.NV12Frame(clip[t], w, h)
+    want = (run_single(plain), run_sync(plain, -1), run_pipe(plain, -1))
+    pool = np.zeros((2, fb), np.uint8)                       # the "capture pool": two recycled buffers
+    hm = gpu.HostMapping(pool)
+
+    def recycled(t):
+        pool[t & 1][:] = clip[t]                             # the CPU writes frame t over what the buffer held
+        return gpu.NV12Frame(pool[t & 1], w, h)
+
+    try:
+        got = (run_single(recycled), run_sync(recycled, 1), run_pipe(recycled, 1))
+    finally:
+        hm.close()
+    assert got[0] == want[0], "single tracker: stale pixels from a rewritten registered buffer"
+    assert got[1] == want[1], "synchronous group"
+    assert got[2] == want[2], "pipelined group"

@@ -10,7 +10,10 @@ run does not pay seconds of CPU oracle per frame.
     prints the minimum and the number of frames below 0.99.
   * teacher-forced tests assert the FLOAT box (StreamState.last_fbox vs the fixture's `fbox`) to 0.15 px,
     closed-loop tests the score to 0.01 on every frame whose input was bit-identical, and the number of
-    frames below IoU 0.99 may not exceed round 3's; the gen-1 head also runs CLOSED loop, bounded at +-2 px.
+    frames below IoU 0.99 may not exceed round 3's count by more than the stated headroom; the gen-1 head also runs CLOSED loop,
+    bounded as ASSERTED there: max <= 5 px, at most 8 % of the frames beyond 2 px, mean IoU >= 0.975 (bars set from the
+    round-4 measurement - max 4 px, 5 % beyond 2 px, mean 0.982-0.985 - so this gate catches a regression of an
+    ill-conditioned head's closed loop, it does not bound the divergence a priori).
   * teacher-forced (open loop) on the FIRST-GENERATION noisy head (fitted on 128 CPU samples only,
     tests/golden/head_gen1_cfg3.npz): before every frame the HIP tracker's state is overwritten with
     the state the oracle had (vt_group_set_state_box), so each frame measures the divergence of ONE
@@ -68,10 +71,13 @@ BARS = {"traj_cfg3_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg3_300_b.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg2_300_b.npz": dict(px=1, min_iou=0.88, mean_iou=0.99),
         "traj_cfg5_300_b.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
-# Round 4: frames with IoU(hip, oracle) < 0.99 (a box off by one pixel in one coordinate) may not grow: bars = the
-# counts of round 3's final run (profiles/r03_gpu_tests.log) for the single tracker / the recommended-size engine.
-LOW_IOU_FRAMES = {"traj_cfg3_300.npz": (1, 1), "traj_cfg2_300.npz": (1, 1), "traj_cfg5_300.npz": (8, 22),
-                  "traj_cfg3_300_b.npz": (5, 6), "traj_cfg2_300_b.npz": (0, 0), "traj_cfg5_300_b.npz": (3, 4)}
+# Frames with IoU(hip, oracle) < 0.99 (a box off by one pixel in one coordinate): MEASURED counts of round 3's final
+# run (profiles/r03_gpu_tests.log) for the single tracker / the recommended-size engine. +-1 px is the guarantee, so a
+# kernel change that moves one bf16 rounding may legitimately move a few of these frames: the bar is the measured
+# count + max(2, 25 %) (round-4 advice), printed beside the measurement.
+LOW_IOU_MEASURED = {"traj_cfg3_300.npz": (1, 1), "traj_cfg2_300.npz": (1, 1), "traj_cfg5_300.npz": (8, 22),
+                    "traj_cfg3_300_b.npz": (5, 6), "traj_cfg2_300_b.npz": (0, 0), "traj_cfg5_300_b.npz": (3, 4)}
+LOW_IOU_FRAMES = {k: tuple(c + max(2, (c + 3) // 4) for c in v) for k, v in LOW_IOU_MEASURED.items()}
 # result.score where both implementations evaluated the SAME input and picked the same cell: closed-loop frames
 # whose incoming state (the previous frame's integer box and success flag) is identical - then the crops are
 # bit-identical and the score differs by one forward pass's bf16 noise only (teacher-forced: <= 0.003 measured)
@@ -364,7 +370,8 @@ def test_closed_loop_on_the_ill_conditioned_first_generation_head(gpu, capsys):
                   f"beyond 1 px at frame {int(np.argmax(d > 1)) if (d > 1).any() else -1}); IoU(hip, oracle) min "
                   f"{ious.min():.4f} mean {ious.mean():.5f}, frames below 0.99: {(ious < 0.99).sum()}; against the ground "
                   f"truth: oracle mean IoU {gt_oracle.mean():.4f} min {gt_oracle.min():.3f}, HIP mean {gt_hip.mean():.4f} "
-                  f"min {gt_hip.min():.3f}")
+                  f"min {gt_hip.min():.3f}  [bars, set from the round-4 run: max <= 5 px, beyond 2 px <= {int(0.08 * n)} frames, "
+                  f"mean IoU >= 0.975, min IoU >= 0.85]")
         assert d.max() <= 5, f"closed loop on the gen-1 head diverged by {d.max()} px at frame {int(d.argmax())}"
         assert (d > 2).sum() <= 0.08 * n and ious.mean() >= 0.975 and ious.min() >= 0.85
         assert np.array_equal(np.array(succ), fx["success"].astype(int)), "success flags differ"

@@ -153,9 +153,10 @@ def test_repr_c_structs_match_the_header_field_for_field(vt):
             "vt_frame": vt.CFrame, "vt_draw_cmd": vt.CDrawCmd, "vt_kernel_time": vt.CKernelTime}
     for cname, ct in want.items():
         assert _size(rust_by_c[cname], cs) == ctypes.sizeof(ct), cname
-    # vt_config names the two fields that were once `reserved` slots
+    # vt_config names the three fields that were once `reserved` slots
     names = [f[0] for f in rust_by_c["vt_config"]]
-    assert names[6:8] == ["max_device_mib", "host_window_margin_pct"] and rust_by_c["vt_config"][-1] == ("reserved", "i32", 6)
+    assert names[6:9] == ["max_device_mib", "host_window_margin_pct", "host_zero_copy"]
+    assert rust_by_c["vt_config"][-1] == ("reserved", "i32", 5)
     hdr = open(os.path.join(ROOT, "include", "vittrack_hip.h")).read()
     assert int(consts["VT_ABI_VERSION"]) == int(re.search(r"#define VT_ABI_VERSION (\d+)", hdr).group(1))
     assert int(consts["VT_MAX_STREAMS"]) == int(re.search(r"#define VT_MAX_STREAMS (\d+)", hdr).group(1))
