@@ -87,9 +87,9 @@ EXPORTS = [
     "vt_recommended_streams", "vt_plan_engines", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_host_register", "vt_host_unregister", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
     "vt_group_host_redos", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
-    "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_state_box", "vt_tracker_as_group",
+    "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_tuning", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
-    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_conv3x3_relu_bf16",
+    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_conv3x3_relu_bf16", "vt_op_headconv_bf16",
     "vt_rccl_unique_id", "vt_broadcast_weights_rccl", "vt_free_device_blob",
 ]
 
@@ -160,6 +160,7 @@ def lib():
     L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
                                           POINTER(CKernelTime), c_int]
     L.vt_group_enable_taps.argtypes = [c_void_p, c_int]
+    L.vt_group_set_tuning.argtypes = [c_void_p, c_char_p, c_int]
     L.vt_group_set_state_box.argtypes = [c_void_p, c_int, POINTER(c_float)]
     L.vt_tracker_as_group.argtypes = [c_void_p]
     L.vt_tracker_as_group.restype = c_void_p
@@ -616,6 +617,10 @@ class Group:
     def enable_taps(self, on=True):
         _check(lib().vt_group_enable_taps(self._h, 1 if on else 0))
 
+    def set_tuning(self, key: str, value: int):
+        """diagnostics: alternative kernels for A/B runs (vt_group_set_tuning)"""
+        _check(lib().vt_group_set_tuning(self._h, key.encode(), int(value)))
+
     def read_tensor(self, name: str, stream: int = 0) -> np.ndarray:
         n = _check(lib().vt_group_read_tensor(self._h, stream, name.encode(), None, 0))
         out = np.empty(n, np.float32)
@@ -742,6 +747,27 @@ def op_conv3x3_relu(t_bf16_bits, w_bf16_bits, bias, B, grid, cfg=-1, device=0):
                                          w.ctypes.data_as(POINTER(ctypes.c_uint16)),
                                          _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, C, N, cfg))
     return out
+
+
+def op_headconv(t_bf16_bits, w_bf16_bits, bias, B, grid, conv3x3=True, R=0, ncb=0, device=0):
+    """vt_op_headconv_bf16: the head's band kernel (k_head.hip) on given operands -> [B*grid*grid][N] float32"""
+    t = np.ascontiguousarray(t_bf16_bits, np.uint16)
+    w = np.ascontiguousarray(w_bf16_bits, np.uint16)
+    Cin, N = t.shape[1], w.shape[0]
+    out = np.empty((t.shape[0], N), np.float32)
+    u16 = POINTER(ctypes.c_uint16)
+    _check(lib().vt_op_headconv_bf16(device, t.ctypes.data_as(u16), w.ctypes.data_as(u16),
+                                     _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, Cin, N,
+                                     1 if conv3x3 else 0, R, ncb, 0, None))
+    return out
+
+
+def op_headconv_bench(B, grid, Cin, N, conv3x3=True, R=0, ncb=0, iters=50, device=0) -> float:
+    """mean microseconds per launch of the band kernel on pseudo-random operands"""
+    us = c_float()
+    _check(lib().vt_op_headconv_bf16(device, None, None, None, None, B, grid, Cin, N, 1 if conv3x3 else 0, R, ncb,
+                                     iters, byref(us)))
+    return float(us.value)
 
 
 def op_layernorm(x, gamma, beta, device=0):

@@ -24,14 +24,14 @@ LIB_HIP = os.path.join(PKG, "libvittrack_hip.so")
 LIB_HOST = os.path.join(HOST, "libvittrack_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_gemm256.hip", "k_attn.hip", "k_misc.hip", "k_overlay.hip",
+HIP_SOURCES = ["k_preproc.hip", "k_gemm.hip", "k_gemm256.hip", "k_attn.hip", "k_misc.hip", "k_head.hip", "k_overlay.hip",
                "vt_engine.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",
              "-Wno-unused-function"]
 # fused multiply-add allowed where no bit-exact float spec applies (MFMA kernels' epilogues and
 # softmax); the pixel stage and the box decode keep one IEEE operation per source operation
-FAST_CONTRACT = {"k_gemm.hip", "k_gemm256.hip", "k_attn.hip"}
+FAST_CONTRACT = {"k_gemm.hip", "k_gemm256.hip", "k_attn.hip"}     # not k_head.hip: its decode keeps one IEEE operation per source operation
 # k_gemm256.hip: hipcc's SLP vectoriser packs the last FMA of the GELU epilogue into v_pk_fma_f32,
 # which has no |x| modifier, so it also emits one v_or per element to build -|x| (and a packed f32
 # op issues at the rate of two scalar ones on CDNA4): 8 % more epilogue VALU for nothing

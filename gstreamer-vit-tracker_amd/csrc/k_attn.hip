@@ -419,6 +419,17 @@ __device__ __forceinline__ float sum_p8(const bf16x8_t& p, float acc) {
     return acc;
 }
 
+// The same sum on the matrix pipe: v_mfma_f32_4x4x4_16b_bf16 with A = ones adds, for every lane, the lane's own four B
+// values to its accumulator (D[i][j] = sum_k 1 * B[k][j] + C[i][j], column j of block lane / 4 = the lane itself; all four
+// result registers are equal) - 2 x 8 cycles of matrix pipe per 8 probabilities instead of 4 v_dot2c (~10 cycles of vector
+// issue each) in a loop that is bound by vector issue.
+__device__ __forceinline__ f32x4_t sum_p8_mfma(const bf16x8_t& p, f32x4_t acc) {
+    const bf16x4_t one4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    const bf16x4_t lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
+    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, hi, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
 }
@@ -440,7 +451,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // two lane halves added once at the end) instead of a third P.V MFMA against a tile of ones - 4 of the 20
 // MFMAs of a step; without the running-maximum bookkeeping the step is bound by the matrix pipe, not by
 // vector issue (profiles/r03_attention_ab.txt).
-template <int ORD, int NS, bool CAREFUL, bool SUMV>
+template <int ORD, int NS, bool CAREFUL, int SUMV>
 __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                          bf16_t* __restrict__ out, int tokens, int H, int npad, int tid, int block) {
     const int lane = tid & 63;
@@ -510,7 +521,8 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     // has been accumulated, only when a maximum leaves that window (upwards in any step; downwards
     // in the first step, so that a row of uniformly tiny scores does not underflow).
     float m_run = 0.0f;
-    float lsum = 0.0f;                   // SUMV: this lane's share of its query's row sum
+    float lsum = 0.0f;                   // SUMV 1: this lane's share of its query's row sum
+    f32x4_t lacc = {0.0f, 0.0f, 0.0f, 0.0f};   // SUMV 2: the same, accumulated by 4x4x4 MFMAs (register 0)
     bool shifted = false;                // wave-uniform: some lane's m_run != 0
     const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
     constexpr int AHEAD = NS - 1;        // tiles in flight beyond the one being computed
@@ -571,6 +583,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
                 if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
         }                                                                                          \
+        if constexpr (careful) {                                                                   \
         if (shifted) {                                                                             \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
         }                                                                                          \
@@ -583,11 +596,12 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);                        \
             m_run += dm;                                                                           \
             shifted = true;                                                                        \
-            osum[0] *= alpha;                                                                      \
+            osum[0] *= alpha; lsum *= alpha; lacc[0] *= alpha;                                     \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
                 o0[r] *= alpha; o1[r] *= alpha;                                                    \
                 S[r] -= dm;                                                                        \
             }                                                                                      \
+        }                                                                                          \
         }                                                                                          \
         bf16x8_t pa, pb;                                                                           \
         {                                                                                          \
@@ -604,10 +618,14 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             const bf16x8_t va1 = AT3_RD(PB_, 8192), vb1 = AT3_RD(PB_, 12288);                      \
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pa, o0, 0, 0, 0);                    \
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pa, o1, 0, 0, 0);                    \
-            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);               \
+            if constexpr (SUMV == 1) lsum = sum_p8(pa, lsum);                                      \
+            else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pa, lacc);                            \
+            else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);          \
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pb, o0, 0, 0, 0);                    \
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pb, o1, 0, 0, 0);                    \
-            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);               \
+            if constexpr (SUMV == 1) lsum = sum_p8(pb, lsum);                                      \
+            else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pb, lacc);                            \
+            else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);          \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
@@ -671,7 +689,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             m_run += dm;                                                                           \
             shifted = true;                                                                        \
             osum[0] *= alpha;                                                                      \
-            lsum *= alpha;                                                                         \
+            lsum *= alpha; lacc[0] *= alpha;                                                       \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
                 o0[r] *= alpha; o1[r] *= alpha;                                                    \
                 S[r] -= dm;                                                                        \
@@ -689,11 +707,13 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         }                                                                                          \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0], pa, o0, 0, 0, 0);                    \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0], pa, o1, 0, 0, 0);                    \
-        if constexpr (SUMV) lsum = sum_p8(pa, lsum);                                               \
+        if constexpr (SUMV == 1) lsum = sum_p8(pa, lsum);                                          \
+        else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pa, lacc);                                \
         else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);              \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0 + 1], pb, o0, 0, 0, 0);                \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0 + 1], pb, o1, 0, 0, 0);                \
-        if constexpr (SUMV) lsum = sum_p8(pb, lsum);                                               \
+        if constexpr (SUMV == 1) lsum = sum_p8(pb, lsum);                                          \
+        else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pb, lacc);                                \
         else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);              \
     }
             AT3_HALF(s0, 0, true, 0)
@@ -730,7 +750,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 m_run += dm;
                 shifted = true;
                 osum[0] *= alpha;
-                lsum *= alpha;
+                lsum *= alpha; lacc[0] *= alpha;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o0[r] *= alpha; o1[r] *= alpha;
@@ -754,7 +774,8 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
-                if constexpr (SUMV) lsum = sum_p8(pf[g], lsum);
+                if constexpr (SUMV == 1) lsum = sum_p8(pf[g], lsum);
+                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pf[g], lacc);
                 else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
             }
         }
@@ -788,11 +809,13 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 8192), c0.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 12288), c0.v, o1, 0, 0, 0);
-                if constexpr (SUMV) lsum = sum_p8(c0.v, lsum);
+                if constexpr (SUMV == 1) lsum = sum_p8(c0.v, lsum);
+                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(c0.v, lacc);
                 else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c0.v, osum, 0, 0, 0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 8192), c1.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 12288), c1.v, o1, 0, 0, 0);
-                if constexpr (SUMV) lsum = sum_p8(c1.v, lsum);
+                if constexpr (SUMV == 1) lsum = sum_p8(c1.v, lsum);
+                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(c1.v, lacc);
                 else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c1.v, osum, 0, 0, 0);
             }
         }
@@ -801,7 +824,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     if constexpr (!careful) {
         // did every query of the workgroup stay in range? (the barriers of a pass are workgroup-wide, so
         // the four waves repeat together or not at all; the flags live in the dead ring)
-        const float l = SUMV ? xhalf_sum(lsum) : osum[0];
+        const float l = SUMV == 1 ? xhalf_sum(lsum) : (SUMV == 2 ? xhalf_sum(lacc[0]) : osum[0]);
         const bool bad = active && !(l >= 0x1p-60f && l <= 0x1p60f);
         const unsigned long long bm = __ballot(bad);
         int* flag = reinterpret_cast<int*>(smem);
@@ -811,7 +834,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         __syncthreads();                  // flags read before anything overwrites them
         if (any) return true;
     }
-    const float l_run = SUMV ? xhalf_sum(lsum) : osum[0];
+    const float l_run = SUMV == 1 ? xhalf_sum(lsum) : (SUMV == 2 ? xhalf_sum(lacc[0]) : osum[0]);
 
     // ---- epilogue: O^T (d on registers, query on lanes) -> LDS [32 q][128 B] per wave -> rows ----
     {
@@ -841,7 +864,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     return false;
 }
 
-template <int ORD, int NS, int WPS, bool SUMV = false>
+template <int ORD, int NS, int WPS, int SUMV = 0>
 __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
@@ -855,7 +878,7 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
         const int k = (int)(blockIdx.x / 256u) % 3;
         for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
-    if constexpr (ORD == 0 || ORD == 1) {
+    if constexpr (ORD == 0 || ORD == 1 || (ORD == 2 && SUMV > 0)) {
         if (at3_pass<ORD, NS, false, SUMV>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
             __syncthreads();
             // the (rare) second pass rebuilds every address from opaque copies of its inputs: if the
@@ -868,7 +891,7 @@ __global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* _
             at3_pass<ORD, NS, true, SUMV>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
         }
     } else {
-        at3_pass<ORD, NS, true, false>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
+        at3_pass<ORD, NS, true, 0>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
     }
 }
 
@@ -906,16 +929,26 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
     } else if (mode == 3) {
         // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc
         // then spills (100 B of scratch) sits in the rare second pass only (checked in the ISA)
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, true>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 7) {               // tuning only: mode 3 with the row sums from a P.V MFMA against ones
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, false>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 0>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 6) {               // tuning only: mode 3 without the unchecked first pass (round 2's kernel)
         hipLaunchKernelGGL((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
-        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 3, true>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 8) {               // tuning: mode 3 with the row sums by 4x4x4 MFMAs (A = ones)
+        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 9) {               // tuning: FOUR workgroups per CU (<= 128 registers, 2-stage ring, sequential halves)
+        // with the unchecked first pass and 4x4x4-MFMA row sums: the one structure round 4 left untried
+        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+                           out, tokens, H, npad, 0);
+    } else if (mode == 10) {              // the same with v_dot2c row sums
+        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 5) {               // 4 workgroups per CU: 2-stage ring, sequential halves in <= 128 registers
         hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,

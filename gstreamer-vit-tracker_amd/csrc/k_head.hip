@@ -1,0 +1,728 @@
+// k_head.hip — the centre head's convolutions for gfx950: 1x1 (D -> C) and 3x3 (C -> C, zero padding)
+// + bias + ReLU -> bf16, and, fused behind the last 3x3 layer, the f32 5-logit layer, the score window,
+// the argmax and the box decode.
+//
+// Why a kernel of its own (round 5). As implicit GEMMs on the 4-wave kernel of k_gemm.hip the four head
+// layers of a 30-stream pass took 93 us at 0.07-0.08 of the MFMA peak: M = 17,280, N = 128 gives 540
+// tiles of 64x64 that each walk all of K = 1152 as a dependent chain of LDS-DMA round trips, and every
+// tile re-fetches its A rows nine times (once per tap). What bounds such a layer is what ONE CU can pull
+// through its vector-memory path (~70 GB/s from L2, MI355X guide "Indexed rows: gather into LDS"), so the
+// kernel is built around bytes per CU:
+//   * a workgroup owns a BAND of R rows of one stream's S x S feature map and all (or half) of the output
+//     channels: 256 CUs x one band each covers a 30-stream pass in one round;
+//   * 3x3 layers: the band's input cells plus a one-cell halo go to LDS ONCE ((R + 2)(S + 2) cells,
+//     zero page for cells outside the map); the nine taps are nine shifted views of that image - the A
+//     operand is read from L2 1.6x instead of 9x;
+//   * the weights stream through a ring of K-tiles (one tap = one K-tile of C channels) filled by LDS-DMA
+//     two tiles ahead, one raw barrier per tap, counted vmcnt;
+//   * 8 waves: four compute (wave w owns output channels [w * BN/4, (w + 1) * BN/4) of every cell of the band:
+//     D^T = W . A^T with v_mfma_f32_16x16x32_bf16, so a lane holds 4 consecutive channels of one cell), four
+//     only issue the LDS-DMA pieces (their issue stalls run beside the MFMA streams, not in them);
+//   * the bf16 tile is assembled in the dead ring and leaves as whole 16-B pieces of contiguous rows.
+// The 1x1 layer (K = D) streams its A rows through the same ring (K-tile depth 64).
+// TAIL (last 3x3 layer): the band's 5 logits per cell are computed from the staged bf16 tile (f32 weights),
+// written with write-through stores; the last band of a stream to arrive (ticket on a per-stream counter,
+// the guide's first valid hand-off form) reads the stream's logits with sc1 loads and decodes the box:
+// head_out and decode are no launches of their own any more (7 -> 4 launches behind the final LayerNorm).
+//
+// Numerics: every output element is one MFMA accumulation chain over k = tap * C + c in ascending order,
+// bias added in f32, ReLU, round-to-nearest-even to bf16 - bit-identical to the implicit-GEMM kernel
+// (tests/test_gpu_ops.py). The decode is the float-op order of vto_decode (oracle/vt_oracle.c).
+#include "vt_common.hpp"
+#include "k_gemm_util.hpp"
+#include <algorithm>
+
+#define HC_MBMAX 7            // row blocks of 16 cells per band (112 cells)
+
+// ---- score window + argmax + box decode of ONE stream (256 threads) ---------------------------------
+// SC1: head_out is read with sc1 loads (handed over by other workgroups of the same launch); plain loads
+// otherwise (written by an earlier launch).
+template <bool SC1>
+__device__ __forceinline__ void load_logits(const float* ho, float (&o)[5]) {
+    if constexpr (SC1) {
+        u32x4_t a; uint32_t b;
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b) : "v"(ho) : "memory");
+        o[0] = __uint_as_float(a[0]); o[1] = __uint_as_float(a[1]); o[2] = __uint_as_float(a[2]);
+        o[3] = __uint_as_float(a[3]); o[4] = __uint_as_float(b);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] = ho[k];
+    }
+}
+
+__device__ __forceinline__ float hc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// better(a, b): candidate a = (response, cell) beats b: larger response, the lower cell on a tie - what "first
+// maximum in ascending cell order" (vto_decode) selects, whatever the order the candidates are combined in
+__device__ __forceinline__ bool hc_better(float ra, int ia, float rb, int ib) { return ra > rb || (ra == rb && ia < ib); }
+
+// The 3x3 window around the argmax cell and the box: threads 0..8 evaluate the window's cells, thread 0 adds the
+// terms in vto_decode's order (dy, dx ascending: bit-identical to the serial form) and writes the result. s_win:
+// 9 x 5 floats + 1 (the argmax cell's score logit) of LDS; every thread of the block calls this (one barrier).
+// pre / pre_po (thread 0 only, may be null): the stream's state and the pass's output addresses as fetched earlier
+// (nothing else writes them during the launch).
+template <bool SC1, bool PRE = false>
+__device__ __forceinline__ void decode_box(const DecodeArgs& a, int b, int idx, int tid, float* s_win,
+                                           const StreamState& pre = StreamState{}, const PassOut& pre_po = PassOut{}) {
+    const int grid = a.grid, ns = a.ns;
+    const int bx = idx % grid, by = idx / grid;
+    if (tid < 9) {
+        const int ix = bx + tid % 3 - 1, iy = by + tid / 3 - 1;
+        float t[5] = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (ix >= 0 && iy >= 0 && ix < grid && iy < grid) {
+            float o[5];
+            load_logits<SC1>(a.head_out + ((size_t)b * ns + iy * grid + ix) * 8, o);
+            const float r = hc_sigmoid(o[0]) * a.hann[iy * grid + ix];
+            const float w = r * r;
+            const float offx = 3.0f * hc_sigmoid(o[1]) - 1.0f;
+            const float offy = 3.0f * hc_sigmoid(o[2]) - 1.0f;
+            const float cxj = ((float)ix + offx) / (float)grid;
+            const float cyj = ((float)iy + offy) / (float)grid;
+            t[0] = w; t[1] = w * cxj; t[2] = w * cyj; t[3] = w * hc_sigmoid(o[3]); t[4] = w * hc_sigmoid(o[4]);
+            if (tid == 4) s_win[45] = o[0];       // the window's centre is the argmax cell
+        } else if (tid == 4) {
+            s_win[45] = __builtin_nanf("");       // no cell had a comparable response (NaN logits): score NaN, success 0
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_win[tid * 5 + k] = t[k];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    StreamState s;
+    if constexpr (PRE) s = pre; else s = a.states[b];
+    const float score = hc_sigmoid(s_win[45]);
+    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
+    for (int j = 0; j < 9; ++j) {
+        if (s_win[j * 5] < 0.0f) continue;
+        sw = sw + s_win[j * 5];
+        scx = scx + s_win[j * 5 + 1];
+        scy = scy + s_win[j * 5 + 2];
+        sbw = sbw + s_win[j * 5 + 3];
+        sbh = sbh + s_win[j * 5 + 4];
+    }
+    const float cxn = scx / sw, cyn = scy / sw, wn = sbw / sw, hn = sbh / sw;
+    const float side = s.geo[3];
+    const float cx = (s.geo[0] + 0.5f) + cxn * side;
+    const float cy = (s.geo[1] + 0.5f) + cyn * side;
+    float bw = wn * side, bh = hn * side;
+    float x1 = cx - 0.5f * bw, y1 = cy - 0.5f * bh;
+    float x2 = x1 + bw, y2 = y1 + bh;
+    const float margin = 10.0f;
+    const float W = (float)s.frame_w, Hh = (float)s.frame_h;
+    x1 = fminf(fmaxf(0.0f, x1), W - margin);
+    y1 = fminf(fmaxf(0.0f, y1), Hh - margin);
+    x2 = fminf(fmaxf(margin, x2), W);
+    y2 = fminf(fmaxf(margin, y2), Hh);
+    bw = fmaxf(margin, x2 - x1);
+    bh = fmaxf(margin, y2 - y1);
+    const int success = (score >= a.success_threshold) ? 1 : 0;
+    vt_result r;
+    r.success = success;
+    r.score = score;
+    r.bbox.x = (int32_t)floorf(x1 + 0.5f);
+    r.bbox.y = (int32_t)floorf(y1 + 0.5f);
+    r.bbox.width = (int32_t)floorf(bw + 0.5f);
+    r.bbox.height = (int32_t)floorf(bh + 0.5f);
+    a.results[b] = r;
+    s.last_fbox[0] = x1; s.last_fbox[1] = y1; s.last_fbox[2] = bw; s.last_fbox[3] = bh;
+    s.last_score = score;
+    s.last_idx = idx;
+    s.frames_done += 1;
+    if (success) {
+        // The state the next frame's crop is cut around is the INTEGER box the caller sees (≙ the
+        // reference's BBox{i32}): two implementations whose boxes agree then cut bit-identical crops
+        // and re-synchronise exactly.
+        s.success_count += 1;
+        s.box[0] = (float)r.bbox.x; s.box[1] = (float)r.bbox.y;
+        s.box[2] = (float)r.bbox.width; s.box[3] = (float)r.bbox.height;
+    }
+    // the host's copies, straight into its pinned memory (visible to it once the pass's event or the
+    // stream synchronises; the fence orders the stores ahead of the kernel's end for every scope)
+    PassOut po;
+    if constexpr (PRE) po = pre_po; else po = *a.out;
+    if (po.host_results) po.host_results[b] = r;
+    if (po.host_states) po.host_states[b] = s;
+    a.states[b] = s;
+    __threadfence_system();
+}
+
+// the whole stream by one block (the decode as a launch of its own): argmax over all cells, then decode_box.
+// smem: >= 2048 + 46 * 4 bytes, 4-B aligned. Same float op order as vto_decode (oracle/vt_oracle.c).
+template <bool SC1>
+__device__ __forceinline__ void decode_stream(const DecodeArgs& a, int b, int tid, char* smem) {
+    float* s_best = reinterpret_cast<float*>(smem);
+    int* s_idx = reinterpret_cast<int*>(smem + 1024);
+    float* s_win = reinterpret_cast<float*>(smem + 2048);
+    const int ns = a.ns;
+    float best = -1.0f;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < ns; i += 256) {
+        float o[5];
+        load_logits<SC1>(a.head_out + ((size_t)b * ns + i) * 8, o);
+        const float resp = hc_sigmoid(o[0]) * a.hann[i];
+        if (hc_better(resp, i, best, bidx)) { best = resp; bidx = i; }
+    }
+    s_best[tid] = best;
+    s_idx[tid] = bidx;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off && hc_better(s_best[tid + off], s_idx[tid + off], s_best[tid], s_idx[tid])) {
+            s_best[tid] = s_best[tid + off];
+            s_idx[tid] = s_idx[tid + off];
+        }
+        __syncthreads();
+    }
+    const int idx = s_idx[0];
+    __syncthreads();
+    decode_box<SC1>(a, b, idx, tid, s_win);
+}
+
+// one block per stream: the decode as a launch of its own (head_out written by an earlier launch)
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[2048 + 48 * 4];
+    decode_stream<false>(a, blockIdx.x, threadIdx.x, smem);
+}
+
+// ---- last head layer (C -> 5 logits, f32): one wave per search token (kept for the engines whose last
+// 3x3 layer runs on the implicit-GEMM kernel, and for the operator tests) ---------------------------
+__global__ __launch_bounds__(256) void head_out_kernel(const bf16_t* __restrict__ t3, const float* __restrict__ w4,
+                                                       const float* __restrict__ b4, float* __restrict__ head_out,
+                                                       int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* row = t3 + (size_t)r * C;
+    float o[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = lane * 2; c < C; c += 128) {
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(row + c);
+        const float t0 = __uint_as_float(pk << 16), t1 = __uint_as_float(pk & 0xffff0000u);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] += t0 * w4[k * C + c] + t1 * w4[k * C + c + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) o[k] += __shfl_xor(o[k], off);
+    if (lane == 0) {
+        float* ho = head_out + (size_t)r * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ho[k] = o[k] + b4[k];
+        ho[5] = ho[6] = ho[7] = 0.0f;
+    }
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
+    if (a.C % 2 != 0) return hipErrorInvalidValue;
+    const int rows = a.B * a.ns;
+    hipLaunchKernelGGL(head_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a.t3, a.w4, a.b4, a.head_out,
+                       rows, a.C);
+    hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- the band kernel -----------------------------------------------------------------------------------
+// HALO: 3x3 layer (A image resident, K-tile = one tap of BK = C channels); else 1x1 layer (A rows stream
+// through the ring, K-tile depth BK = 64). NCB: 16-column blocks per wave (BN = 64 * NCB output channels per
+// workgroup). MB: row blocks of 16 cells per band, a compile-time constant so that the main loop is straight-line
+// code with its LDS reads hoisted over the MFMAs (with a run-time count hipcc split the loop body into one basic
+// block per row block, each waiting for its own read); a short last band computes its padding blocks on the
+// band's last cell and stores nothing for them. TAIL: + logits + decode (needs BN = N = C).
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), every lane gets the same bits: two quad_perm moves,
+// row_half_mirror, row_mirror - no LDS round trip (a ds_bpermute butterfly was 20 dependent LDS trips per cell group)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+// the same over 8 lanes (lanes 8k .. 8k+7)
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+// 512 threads: waves 0-3 compute (one per SIMD; wave w owns output channels [w * BN/4, (w + 1) * BN/4) of every cell of
+// the band), waves 4-7 are LOADERS: every LDS-DMA of the kernel is theirs. One global_load_lds costs the issuing wave ~100
+// cycles of back-pressure from the CU's vector-memory path (a tap's 8 pieces per wave = longer than its 40 MFMAs); issued
+// by the computing waves themselves (first version) the two added up - 12.3 us per 30-stream layer, of which the loop was
+// issue stalls; a loader wave stalls beside a computing wave's MFMA stream instead (the guide's ring-gemm structure).
+// One raw barrier per K-tile for all eight waves: the loaders pass it after their counted vmcnt (tile kt has landed),
+// the computing waves after the MFMAs of tile kt - 1 (its stage may be refilled).
+template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+__global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeArgs dec) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 512;
+    constexpr int ROWB = BK * 2;                  // bytes per LDS row: one cell's channels of a tap / one K-tile row
+    constexpr int CPR = ROWB / 16;                // 16-B chunks per row (8 or 16)
+    constexpr int RPP = 1024 / ROWB;              // rows per 1-KiB LDS-DMA piece (8 or 4)
+    constexpr int BN = 64 * NCB;
+    constexpr int NS = HALO ? 3 : 4;              // ring stages
+    constexpr int WPW = BN / RPP / 4;             // W pieces per loader wave and stage
+    static_assert(BK == 64 || BK == 128, "K-tile depth");
+    static_assert(!TAIL || HALO, "the fused tail follows a 3x3 layer");
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : row & 15; };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;                // wave-uniform
+    const int w4 = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // which band: blockIdx.x = (stream * bands + band) * ncol + column group
+    const int ncol = p.N / BN;
+    const int cg = blockIdx.x % ncol, bb = blockIdx.x / ncol;
+    const int band = bb % p.bands, b = bb / p.bands;
+    const int grid = p.grid, ns = grid * grid;
+    const int y0 = band * p.R;
+    const int rows_eff = min(p.R, grid - y0);
+    const int cells = rows_eff * grid;            // output cells of this band (<= 16 * MB)
+    const int m_base = b * ns + y0 * grid;        // first output row of the band in [B * ns][N]
+    const int n0 = cg * BN;
+
+    // LDS: [A image (HALO) | ring of NS stages]; a stage = [A rows (stream mode) | BN weight rows]
+    const int hw = grid + 2;
+    const int hcells = HALO ? (p.R + 2) * hw : 0;
+    const int himg = HALO ? ((hcells + RPP - 1) / RPP) * RPP * ROWB : 0;
+    constexpr int MBE = (MB + 1) & ~1;            // stream mode: an even number of row blocks (pieces divide over 4 waves)
+    constexpr int a_stage = HALO ? 0 : MBE * 16 * ROWB;
+    constexpr int stage = a_stage + BN * ROWB;
+    constexpr int APW = HALO ? 0 : MBE / 2;        // stream mode: MBE / 2 pieces of 8 rows per loader wave (ROWB 128)
+    constexpr int IPS = WPW + APW;                 // LDS-DMA pieces per loader wave and stage
+    char* ring = smem + himg;
+    const int ntile = HALO ? 9 : p.K / BK;
+
+    // the fused tail's operands that do not depend on the layer's result are fetched BEFORE the main loop (plain loads,
+    // consumed behind it): the logit weights of this lane's 8 channels, the Hann values of its cells, and - thread 0 -
+    // the stream state and the pass's output addresses. Behind the loop each was a dependent round trip at the very
+    // end of the pass.
+    constexpr int LPC = CPR;                      // TAIL: lanes per cell (8 channels each)
+    constexpr int CPI = NT / LPC;                 // cells per iteration of the logits loop
+    constexpr int NIT = (MB * 16 + CPI - 1) / CPI;
+    const int sub = tid % LPC;
+    float w4r[5][8], hannr[NIT], b4r[5];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(dec.w4 + k * BN + sub * 8);
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(dec.w4 + k * BN + sub * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w4r[k][e] = lo[e]; w4r[k][4 + e] = hi[e]; }
+            b4r[k] = dec.b4[k];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cell = it * CPI + tid / LPC;
+            hannr[it] = dec.hann[y0 * grid + (cell < cells ? cell : cells - 1)];
+        }
+    }
+
+    f32x4_t acc[MB][NCB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (loader) {
+        // ---- loader waves: A image, then the ring -------------------------------------------------------------
+        if constexpr (HALO) {
+            const int npieces = himg / 1024;
+            for (int pc = w4; pc < npieces; pc += 4) {
+                const int h = pc * RPP + lane / CPR;                 // halo cell of this lane
+                const int c = (lane % CPR) ^ swz(h);                 // global chunk that lands in LDS chunk slot lane % CPR
+                const int hy = h / hw, hx = h - hy * hw;
+                const int y = y0 + hy - 1, x = hx - 1;
+                const bool in = h < hcells && y >= 0 && y < grid && x >= 0 && x < grid;
+                const bf16_t* src = in ? p.in + ((size_t)(b * ns + y * grid + x)) * p.ldin + c * 8 : p.zeros + c * 8;
+                glds16(src, smem + pc * 1024);
+            }
+        }
+        // per-lane source pointers of the pieces this wave issues per stage
+        const bf16_t* wsrc[WPW];
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int row = (w4 * WPW + j) * RPP + lane / CPR;
+            const int c = (lane % CPR) ^ swz(row);
+            wsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
+        }
+        const bf16_t* asrc[APW + 1];
+        if constexpr (!HALO) {
+#pragma unroll
+            for (int j = 0; j < APW; ++j) {
+                const int row = (w4 * APW + j) * RPP + lane / CPR;
+                const int c = (lane % CPR) ^ swz(row);
+                const int rc = row < cells ? row : cells - 1;        // padding rows repeat the last cell, never stored
+                asrc[j] = p.in + (size_t)(m_base + rc) * p.ldin + c * 8;
+            }
+        }
+        auto issue_tile = [&](int kt, int buf) {
+            char* st = ring + buf * stage;
+#pragma unroll
+            for (int q = 0; q < APW; ++q) glds16(asrc[q] + kt * BK, st + (w4 * APW + q) * 1024);
+#pragma unroll
+            for (int q = 0; q < WPW; ++q) glds16(wsrc[q] + kt * BK, st + a_stage + (w4 * WPW + q) * 1024);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NS - 1; ++s_)
+            if (s_ < ntile) issue_tile(s_, s_);
+        int cur = 0;
+        for (int kt = 0; kt < ntile; ++kt) {
+            const int ahead = min(NS - 2, ntile - 1 - kt);       // tiles that may stay in flight behind tile kt
+            if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * IPS>();
+            else if (ahead >= 1) wait_vmcnt<IPS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();           // tile kt has landed; the computing waves are done with tile kt - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS - 1 < ntile) issue_tile(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+        }
+    } else {
+        // ---- computing waves -------------------------------------------------------------------------------------
+        // fragment addresses. W rows of this wave: wave * 16 * NCB + j * 16 + l15
+        int woff[NCB], wsw[NCB];
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int row = w4 * 16 * NCB + j * 16 + l15;
+            woff[j] = a_stage + row * ROWB;
+            wsw[j] = swz(row);
+        }
+        // A rows: cell i * 16 + l15 of the band (padding rows use the band's last cell)
+        int h0[MB];                                    // HALO: halo index of the cell's tap (0, 0); else LDS row
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            int cell = i * 16 + l15;
+            cell = cell < cells ? cell : cells - 1;
+            if constexpr (HALO) {
+                const int y = cell / grid, x = cell - y * grid;
+                h0[i] = y * hw + x;
+            } else {
+                h0[i] = i * 16 + l15;
+            }
+        }
+        int cur = 0;
+        for (int kt = 0; kt < ntile; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const char* st = ring + cur * stage;
+            int aoff[MB], asw[MB];
+            if constexpr (HALO) {
+                const int ky = kt / 3, kx = kt - 3 * ky;
+                const int toff = ky * hw + kx;
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int h = h0[i] + toff;
+                    aoff[i] = h * ROWB;
+                    asw[i] = swz(h);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    aoff[i] = h0[i] * ROWB;
+                    asw[i] = swz(h0[i]);
+                }
+            }
+            const char* abase = HALO ? smem : st;
+            constexpr int KS = BK / 32;
+            // k-steps software-pipelined inside the wave (one computing wave per SIMD: nobody else hides an LDS round
+            // trip): the fragments of step ks + 1 are read while the MFMAs of step ks issue
+            bf16x8_t wf[2][NCB], af[2][MB];
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) wf[0][j] = *reinterpret_cast<const bf16x8_t*>(st + woff[j] + ((lq ^ wsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[0][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((lq ^ asw[i]) << 4));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cb = ks & 1, nb = cb ^ 1;
+                if (ks + 1 < KS) {
+                    const int ch = (ks + 1) * 4 + lq;
+#pragma unroll
+                    for (int j = 0; j < NCB; ++j)
+                        wf[nb][j] = *reinterpret_cast<const bf16x8_t*>(st + woff[j] + ((ch ^ wsw[j]) << 4));
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+                        af[nb][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((ch ^ asw[i]) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NCB; ++j)   // D[n][m]: rows = output channels (registers), columns = cells (lanes)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+            }
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+        }
+    }
+    __syncthreads();                               // every wave is done with the ring (no LDS-DMA outstanding)
+    // TAIL: the stream's state and the pass's output addresses, for the workgroup that will turn out to be the stream's
+    // last: fetched here by thread 0 with inline-asm loads (hipcc would sink plain loads to their use - a dependent round
+    // trip at the very end of the pass - or, hoisted above the main loop, spill them around it), consumed behind the
+    // ticket; nothing else writes them during this launch.
+    uint2 pre_s[11], pre_o[2];                     // 8-B loads: both structs are 8-B aligned in their arrays
+    static_assert(sizeof(StreamState) == 88 && sizeof(PassOut) == 16, "prefetch layout");
+    if constexpr (TAIL) {
+        if (tid == 0) {
+            const char* sp = reinterpret_cast<const char*>(dec.states + b);
+            const char* op = reinterpret_cast<const char*>(dec.out);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_s[i]) : "v"(sp + 8 * i) : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre_o[i]) : "v"(op + 8 * i) : "memory");
+        }
+    }
+
+    // ---- epilogue: bias + ReLU -> bf16 tile [cells][BN] in the dead ring -> whole rows out ------------------
+    constexpr int OSTR = BN * 2 + 16;              // padded row: 8-B writes of 16 lanes in 16 rows hit distinct banks
+    char* otile = ring;
+    if (!loader) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int nl = w4 * 16 * NCB + j * 16 + 4 * lq;          // this lane's 4 consecutive channels
+            const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + nl);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int m = i * 16 + l15;
+                const float v0 = fmaxf(acc[i][j][0] + bias[0], 0.0f), v1 = fmaxf(acc[i][j][1] + bias[1], 0.0f);
+                const float v2 = fmaxf(acc[i][j][2] + bias[2], 0.0f), v3 = fmaxf(acc[i][j][3] + bias[3], 0.0f);
+                *reinterpret_cast<uint2*>(otile + m * OSTR + nl * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CH = BN / 8;                 // 16-B pieces per row
+        for (int c = tid; c < cells * CH; c += NT) {
+            const int r = c / CH, ch = c - r * CH;
+            *reinterpret_cast<uint4*>(p.out + (size_t)(m_base + r) * p.ldout + n0 + ch * 8) =
+                *reinterpret_cast<const uint4*>(otile + r * OSTR + ch * 16);
+        }
+    }
+    if constexpr (TAIL) {
+        // ---- 5 logits per cell from the staged tile: LPC lanes x 8 channels per cell, f32 weights ------------------
+        // (BN = N = C = BK here: a row is CPR chunks of 8 channels). The band's own argmax candidate: response =
+        // sigmoid(score logit) * hann, kept in the (dead) A image.
+        float* s_resp = reinterpret_cast<float*>(smem + 64);          // [MB * 16]
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cell = it * CPI + tid / LPC;
+            const int cc = cell < cells ? cell : cells - 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(otile + cc * OSTR + sub * 16);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+            float o[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t0 = __uint_as_float(u[e] << 16), t1 = __uint_as_float(u[e] & 0xffff0000u);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) o[k] += t0 * w4r[k][2 * e] + t1 * w4r[k][2 * e + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = (LPC == 16 ? row16_sum(o[k]) : row8_sum(o[k])) + b4r[k];
+            if (sub == 0) {
+                if (cell < cells) {
+                    float* ho = dec.head_out + (size_t)(m_base + cell) * 8;
+                    const u32x4_t a = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                    const u32x4_t z = {__float_as_uint(o[4]), 0u, 0u, 0u};
+                    // write-through: read by another workgroup of this launch (sc1 loads) after the ticket below
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                                 : : "v"(ho), "v"(a), "v"(z) : "memory");
+                }
+                if (cell < MB * 16)
+                    s_resp[cell] = cell < cells ? hc_sigmoid(o[0]) * hannr[it] : -3.0f;   // padding: never a candidate
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                          // first maximum of the band -> one 8-B candidate
+            float best = -2.0f;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < MB * 16; c += 64) {
+                const int cell = c + lane;
+                if (cell < MB * 16) {
+                    const float r = s_resp[cell];
+                    const int gi = y0 * grid + cell;
+                    if (hc_better(r, gi, best, bidx)) { best = r; bidx = gi; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bidx, off);
+                if (hc_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+            }
+            if (lane == 0) {
+                float* cand = p.band_best + 2 * ((size_t)b * p.bands + band);
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(cand), "v"(make_uint2(__float_as_uint(best), (uint32_t)bidx)) : "memory");
+            }
+        }
+        // ---- hand-off: the last band of the stream to arrive decodes it ------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave, before the barrier
+        __syncthreads();
+        int* s_last = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(p.band_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)(p.bands - 1);
+            if (last) __hip_atomic_store(p.band_cnt + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last[0] = last;
+        }
+        __syncthreads();
+        if (!s_last[0]) return;                     // workgroup-uniform
+        // the stream's argmax from the bands' candidates (one sc1 load per band), then the window and the box
+        if (wave == 0) {
+            float best = -2.0f;
+            int bidx = 0x7fffffff;
+            for (int c = lane; c < p.bands; c += 64) {
+                uint2 v;
+                asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(v) : "v"(p.band_best + 2 * ((size_t)b * p.bands + c)) : "memory");
+                const float r = __uint_as_float(v.x);
+                if (hc_better(r, (int)v.y, best, bidx)) { best = r; bidx = (int)v.y; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bidx, off);
+                if (hc_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+            }
+            if (lane == 0) s_last[1] = bidx;
+        }
+        __syncthreads();
+        const int idx = s_last[1];
+        StreamState pre_state;
+        PassOut pre_po;
+        if (tid == 0) {
+            vm_drain();
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_s[0]), "+v"(pre_s[1]), "+v"(pre_s[2]), "+v"(pre_s[3]), "+v"(pre_s[4]),
+                         "+v"(pre_s[5]), "+v"(pre_s[6]), "+v"(pre_s[7]), "+v"(pre_s[8]), "+v"(pre_s[9]), "+v"(pre_s[10]),
+                         "+v"(pre_o[0]), "+v"(pre_o[1]) : : "memory");
+            uint32_t w[22];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) { w[2 * i] = pre_s[i].x; w[2 * i + 1] = pre_s[i].y; }
+            __builtin_memcpy(&pre_state, w, 88);
+            const uint32_t q[4] = {pre_o[0].x, pre_o[0].y, pre_o[1].x, pre_o[1].y};
+            __builtin_memcpy(&pre_po, q, 16);
+        }
+        decode_box<true, true>(dec, b, idx, tid, reinterpret_cast<float*>(smem + 64), pre_state, pre_po);
+    }
+}
+
+// ---- launch plan -----------------------------------------------------------------------------------------
+// Rows per band R and column groups: one round of workgroups over the 256 CUs where the batch allows it, and
+// the least bytes through one CU (the weights of its column group + its A image): see the header.
+static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool tail, int* R_out, int* ncb_out) {
+    double best = 1e30;
+    int bestR = 1, bestncb = N >= 128 ? 2 : 1;
+    for (int ncb = (N % 128 == 0) ? 2 : 1; ncb >= 1; --ncb) {
+        const int BN = 64 * ncb;
+        if (N % BN) continue;
+        if (tail && BN != N) continue;
+        for (int R = 1; R <= grid; ++R) {
+            const int mb = (R * grid + 15) / 16;
+            if (mb > HC_MBMAX) break;
+            const int bands = (grid + R - 1) / R;
+            const long wgs = (long)B * bands * (N / BN);
+            const long rounds = (wgs + 255) / 256;
+            const double wbytes = (double)BN * K * 2;
+            const double abytes = halo ? (double)(R + 2) * (grid + 2) * C * 2 : (double)mb * 16 * K * 2;
+            const double stream_us = (wbytes + abytes) / 70e3;              // ~70 GB/s per CU from L2
+            const double mfma_us = (double)mb * ncb * (K / 32) * 16 / 1.9e3;  // 16 cycles per MFMA, one wave per SIMD
+            const double t = rounds * (std::max(stream_us, mfma_us) + 0.5) + 0.002 * bands;
+            if (t < best) { best = t; bestR = R; bestncb = ncb; }
+        }
+    }
+    *R_out = bestR; *ncb_out = bestncb;
+}
+
+template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+static hipError_t headconv_launch_t(const HeadConvArgs& a, const DecodeArgs& dec, int wgs, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL((head_conv_kernel<BK, NCB, MB, HALO, TAIL>), dim3(wgs), dim3(512), smem, st, a, dec);
+    return hipGetLastError();
+}
+template <int BK, int NCB, bool HALO, bool TAIL>
+static hipError_t headconv_launch_mb(int mb, const HeadConvArgs& a, const DecodeArgs& dec, int wgs, size_t smem, hipStream_t st) {
+    switch (mb) {
+        case 1: return headconv_launch_t<BK, NCB, 1, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 2: return headconv_launch_t<BK, NCB, 2, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 3: return headconv_launch_t<BK, NCB, 3, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 4: return headconv_launch_t<BK, NCB, 4, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 5: return headconv_launch_t<BK, NCB, 5, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 6: return headconv_launch_t<BK, NCB, 6, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 7: return headconv_launch_t<BK, NCB, 7, HALO, TAIL>(a, dec, wgs, smem, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+static hipError_t headconv_prep_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&head_conv_kernel<BK, NCB, MB, HALO, TAIL>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int BK, int NCB, bool HALO, bool TAIL>
+static hipError_t headconv_prep_mb() {
+    hipError_t e = headconv_prep_t<BK, NCB, 1, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 2, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 3, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 4, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 5, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 6, HALO, TAIL>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 7, HALO, TAIL>();
+    return e;
+}
+
+// Raise the dynamic-LDS limit of every instantiation once per device, outside any stream capture.
+hipError_t headconv_prepare() {
+    hipError_t e = headconv_prep_mb<128, 1, true, false>();
+    if (e == hipSuccess) e = headconv_prep_mb<128, 2, true, false>();
+    if (e == hipSuccess) e = headconv_prep_mb<128, 2, true, true>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 1, true, false>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 1, true, true>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 1, false, false>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 2, false, false>();
+    return e;
+}
+
+bool headconv_supported(int grid, int C, int N, int K, bool conv3x3) {
+    if (grid < 1 || grid > 16 * HC_MBMAX) return false;
+    if (conv3x3) return (C == 64 || C == 128) && N == C && K == 9 * C;
+    return (N == 64 || N == 128) && K % 64 == 0 && K >= 64;
+}
+
+// a.R <= 0: planned here. dec != nullptr: the fused tail (logits + decode) behind a 3x3 layer.
+hipError_t launch_headconv(HeadConvArgs a, const DecodeArgs* dec, hipStream_t st) {
+    const bool halo = a.conv3x3 != 0, tail = dec != nullptr;
+    if (a.B < 1 || !a.in || !a.W || !a.bias || !a.out) return hipErrorInvalidValue;
+    if (!headconv_supported(a.grid, a.C, a.N, a.K, halo)) return hipErrorInvalidValue;
+    if (halo && (!a.zeros || a.ldin < a.C)) return hipErrorInvalidValue;
+    if (tail && (!halo || !a.band_cnt || !a.band_best || !dec->w4 || !dec->b4 || !dec->head_out || !dec->hann || !dec->states ||
+                 !dec->results || !dec->out || dec->ns != a.grid * a.grid || dec->B != a.B || dec->grid != a.grid))
+        return hipErrorInvalidValue;
+    int R = a.R, ncb = a.ncb;
+    if (R <= 0 || ncb <= 0) headconv_plan(a.B, a.grid, a.C, a.N, a.K, halo, tail, &R, &ncb);
+    if (R > a.grid) R = a.grid;
+    const int BN = 64 * ncb, mbmax = (R * a.grid + 15) / 16;
+    if (mbmax > HC_MBMAX || a.N % BN || (tail && BN != a.N)) return hipErrorInvalidValue;
+    a.R = R; a.ncb = ncb;
+    a.bands = (a.grid + R - 1) / R;
+    a.mbe_max = (mbmax + 1) & ~1;
+    const int BK = halo ? a.C : 64, rowb = BK * 2, rpp = 1024 / rowb;
+    const size_t himg = halo ? (size_t)(((R + 2) * (a.grid + 2) + rpp - 1) / rpp) * rpp * rowb : 0;
+    const size_t stage = (halo ? 0 : (size_t)a.mbe_max * 16 * rowb) + (size_t)BN * rowb;
+    const size_t ring = (halo ? 3 : 4) * stage;
+    const size_t otile = (size_t)mbmax * 16 * (BN * 2 + 16);
+    const size_t smem = himg + std::max(ring, std::max(otile, (size_t)8192));
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    const int wgs = a.B * a.bands * (a.N / BN);
+    DecodeArgs d{};
+    if (dec) d = *dec;
+    const int mb = mbmax;
+    if (halo && BK == 128) {
+        if (tail) return headconv_launch_mb<128, 2, true, true>(mb, a, d, wgs, smem, st);
+        return ncb == 2 ? headconv_launch_mb<128, 2, true, false>(mb, a, d, wgs, smem, st)
+                        : headconv_launch_mb<128, 1, true, false>(mb, a, d, wgs, smem, st);
+    }
+    if (halo) {
+        return tail ? headconv_launch_mb<64, 1, true, true>(mb, a, d, wgs, smem, st)
+                    : headconv_launch_mb<64, 1, true, false>(mb, a, d, wgs, smem, st);
+    }
+    return ncb == 2 ? headconv_launch_mb<64, 2, false, false>(mb, a, d, wgs, smem, st)
+                    : headconv_launch_mb<64, 1, false, false>(mb, a, d, wgs, smem, st);
+}

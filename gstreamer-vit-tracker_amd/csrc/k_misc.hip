@@ -1,4 +1,4 @@
-// k_misc.hip — LayerNorm, the head's last layer and the on-device box decode for gfx950.
+// k_misc.hip — LayerNorm, row statistics and the LayerNorm fold for gfx950 (the head lives in k_head.hip).
 #include "vt_common.hpp"
 
 // ---- LayerNorm: one wave per row, row kept in registers, two-pass variance -----------------------
@@ -268,173 +268,5 @@ hipError_t launch_fold_layernorm(const bf16_t* W, const float* gamma, const floa
     if (N <= 0 || K <= 0 || (K & 1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wf, colsum,
                        cvec, N, K);
-    return hipGetLastError();
-}
-
-// ---- last head layer (C -> 5 logits, f32): one wave per search token -----------------------------
-// lanes stride over the channels, five dot products, wave reduction. Kept apart from the decode so
-// that it runs token-parallel over the whole chip (as one block per stream it was a 40 us serial
-// tail of every frame).
-__global__ __launch_bounds__(256) void head_out_kernel(const bf16_t* __restrict__ t3,
-                                                       const float* __restrict__ w4,
-                                                       const float* __restrict__ b4,
-                                                       float* __restrict__ head_out, int rows,
-                                                       int C) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const bf16_t* row = t3 + (size_t)r * C;
-    float o[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c = lane * 2; c < C; c += 128) {
-        const uint32_t pk = *reinterpret_cast<const uint32_t*>(row + c);
-        const float t0 = __uint_as_float(pk << 16), t1 = __uint_as_float(pk & 0xffff0000u);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o[k] += t0 * w4[k * C + c] + t1 * w4[k * C + c + 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) o[k] += __shfl_xor(o[k], off);
-    if (lane == 0) {
-        float* ho = head_out + (size_t)r * 8;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) ho[k] = o[k] + b4[k];
-        ho[5] = ho[6] = ho[7] = 0.0f;
-    }
-}
-
-// ---- score window + argmax + box decode -------------------------------------------------------------
-// One 256-thread block per stream. Writes vt_result and the stream state the next frame's
-// preprocessing reads. Same float op order as vto_decode (oracle/vt_oracle.c).
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
-    __shared__ float s_best[256];
-    __shared__ int s_idx[256];
-    __shared__ float s_logit[256][5];  // logits of each thread's own best cell
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int ns = a.ns;
-    float best = -1.0f;
-    int bidx = 0x7fffffff;
-    float bo[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int i = tid; i < ns; i += 256) {
-        const float* ho = a.head_out + ((size_t)b * ns + i) * 8;
-        float o[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) o[k] = ho[k];
-        const float resp = sigmoidf_(o[0]) * a.hann[i];
-        if (resp > best) {  // ascending i per thread: first max kept
-            best = resp; bidx = i;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) bo[k] = o[k];
-        }
-    }
-    s_best[tid] = best;
-    s_idx[tid] = bidx;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s_logit[tid][k] = bo[k];
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) {
-            const float ob = s_best[tid + off];
-            const int oi = s_idx[tid + off];
-            if (ob > s_best[tid] || (ob == s_best[tid] && oi < s_idx[tid])) {
-                s_best[tid] = ob;
-                s_idx[tid] = oi;
-            }
-        }
-        __syncthreads();
-    }
-    // the 3x3 window around the argmax: its nine cells are evaluated by nine lanes at once (the loads and
-    // the five sigmoids of a cell are independent of the other cells - done one after the other by one
-    // lane they were nine dependent round trips at the end of every pass), then lane 0 adds the terms in
-    // vto_decode's order (dy, dx ascending), so the sums are bit-identical to the serial form
-    __shared__ float s_win[9][5];      // w, w*cx, w*cy, w*sig(o3), w*sig(o4); w < 0: cell outside the map
-    const int idx = s_idx[0];
-    const int grid = a.grid;
-    const int bx = idx % grid, by = idx / grid;
-    if (tid < 9) {
-        const int ix = bx + tid % 3 - 1, iy = by + tid / 3 - 1;
-        float t[5] = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (ix >= 0 && iy >= 0 && ix < grid && iy < grid) {
-            const float* o = a.head_out + ((size_t)b * ns + iy * grid + ix) * 8;
-            const float r = sigmoidf_(o[0]) * a.hann[iy * grid + ix];
-            const float w = r * r;
-            const float offx = 3.0f * sigmoidf_(o[1]) - 1.0f;
-            const float offy = 3.0f * sigmoidf_(o[2]) - 1.0f;
-            const float cxj = ((float)ix + offx) / (float)grid;
-            const float cyj = ((float)iy + offy) / (float)grid;
-            t[0] = w; t[1] = w * cxj; t[2] = w * cyj; t[3] = w * sigmoidf_(o[3]); t[4] = w * sigmoidf_(o[4]);
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) s_win[tid][k] = t[k];
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    StreamState& s = a.states[b];
-    const float score = sigmoidf_(s_logit[idx & 255][0]);  // cell i is handled by thread i % 256
-    // response^2-weighted mean over the window (see vto_decode); head_out was written by the preceding
-    // head_out_kernel launch.
-    float sw = 0.0f, scx = 0.0f, scy = 0.0f, sbw = 0.0f, sbh = 0.0f;
-    for (int j = 0; j < 9; ++j) {
-        if (s_win[j][0] < 0.0f) continue;
-        sw = sw + s_win[j][0];
-        scx = scx + s_win[j][1];
-        scy = scy + s_win[j][2];
-        sbw = sbw + s_win[j][3];
-        sbh = sbh + s_win[j][4];
-    }
-    const float cxn = scx / sw, cyn = scy / sw, wn = sbw / sw, hn = sbh / sw;
-    const float side = s.geo[3];
-    const float cx = (s.geo[0] + 0.5f) + cxn * side;
-    const float cy = (s.geo[1] + 0.5f) + cyn * side;
-    float bw = wn * side, bh = hn * side;
-    float x1 = cx - 0.5f * bw, y1 = cy - 0.5f * bh;
-    float x2 = x1 + bw, y2 = y1 + bh;
-    const float margin = 10.0f;
-    const float W = (float)s.frame_w, Hh = (float)s.frame_h;
-    x1 = fminf(fmaxf(0.0f, x1), W - margin);
-    y1 = fminf(fmaxf(0.0f, y1), Hh - margin);
-    x2 = fminf(fmaxf(margin, x2), W);
-    y2 = fminf(fmaxf(margin, y2), Hh);
-    bw = fmaxf(margin, x2 - x1);
-    bh = fmaxf(margin, y2 - y1);
-    const int success = (score >= a.success_threshold) ? 1 : 0;
-    vt_result r;
-    r.success = success;
-    r.score = score;
-    r.bbox.x = (int32_t)floorf(x1 + 0.5f);
-    r.bbox.y = (int32_t)floorf(y1 + 0.5f);
-    r.bbox.width = (int32_t)floorf(bw + 0.5f);
-    r.bbox.height = (int32_t)floorf(bh + 0.5f);
-    a.results[b] = r;
-    s.last_fbox[0] = x1; s.last_fbox[1] = y1; s.last_fbox[2] = bw; s.last_fbox[3] = bh;
-    s.last_score = score;
-    s.last_idx = idx;
-    s.frames_done += 1;
-    if (success) {
-        // The state the next frame's crop is cut around is the INTEGER box the caller sees (≙ the
-        // reference's BBox{i32}). With a float state a 0.01 px difference between two
-        // implementations persists and is amplified whenever the target sits near a cell boundary
-        // (measured: up to 1.5 px over ~10 frames); with the rounded state both see bit-identical
-        // crops whenever their boxes agree, so they re-synchronise exactly.
-        s.success_count += 1;
-        s.box[0] = (float)r.bbox.x; s.box[1] = (float)r.bbox.y;
-        s.box[2] = (float)r.bbox.width; s.box[3] = (float)r.bbox.height;
-    }
-    // the host's copies, straight into its pinned memory (visible to it once the pass's event or the
-    // stream synchronises; the fence orders the stores ahead of the kernel's end for every scope)
-    const PassOut po = *a.out;
-    if (po.host_results) po.host_results[b] = r;
-    if (po.host_states) po.host_states[b] = s;
-    __threadfence_system();
-}
-
-hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
-    if (a.C % 2 != 0) return hipErrorInvalidValue;
-    const int rows = a.B * a.ns;
-    hipLaunchKernelGGL(head_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a.t3, a.w4, a.b4, a.head_out,
-                       rows, a.C);
-    hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -190,7 +190,29 @@ struct DecodeArgs {
     int B, ns, grid, C;
     float success_threshold;
 };
-hipError_t launch_decode(const DecodeArgs& a, hipStream_t st);
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t st);     // head_out_kernel + decode_kernel (two launches)
+
+// The head's convolutions on the band kernel of k_head.hip: out[B*grid*grid][N] bf16 = relu(conv(in) + bias).
+// conv3x3: in [B*grid*grid][C] (ldin >= C), W [N][9*C] with column (ky*3+kx)*C + c, zero padding (zeros: >= 256 B
+// of zeros in device memory), N == C; else a 1x1 layer: in [B*grid*grid][K], W [N][K].
+struct HeadConvArgs {
+    const bf16_t* in; int ldin;
+    const bf16_t* W; int ldw;
+    const float* bias;
+    bf16_t* out; int ldout;
+    const bf16_t* zeros;
+    int B, grid, C, N, K;
+    int conv3x3;
+    int R, ncb;                 // rows per band / 16-column blocks per wave; <= 0: planned by the launcher
+    unsigned* band_cnt;         // fused tail only: [B] arrival counters, zero between launches
+    float* band_best;           // fused tail only: [B][bands][2] each band's argmax candidate (response, cell), bands <= grid
+    int bands, mbe_max;         // filled in by the launcher
+};
+bool headconv_supported(int grid, int C, int N, int K, bool conv3x3);
+hipError_t headconv_prepare();     // once per device, before the first launch / any stream capture
+// dec != nullptr (3x3 layers only): the 5-logit layer, the score window, the argmax and the box decode run inside
+// the same launch (dec->t3 is ignored: the logits are computed from the layer's own output tile)
+hipError_t launch_headconv(HeadConvArgs a, const DecodeArgs* dec, hipStream_t st);
 
 // ---- small device helpers ---------------------------------------------------------------------
 

@@ -141,6 +141,8 @@ struct Engine {
     // residual stream as a bf16 pair (x = xh + xl), its chunk partial statistics and the row terms of the
     // folded LayerNorm (vt_common.hpp); folded weights of all layers
     bf16_t *d_xh = nullptr, *d_xl = nullptr, *d_foldw = nullptr, *d_taps = nullptr;
+    unsigned* d_band_cnt = nullptr;               // per stream: bands of the last head layer that have arrived (k_head.hip)
+    float* d_band_best = nullptr;                 // per stream and band: the band's argmax candidate
     float2 *d_cstat = nullptr, *d_rstat = nullptr;
     unsigned* d_panel_cnt = nullptr;   // arrival counters of the 256-row panels (X-epilogues of the 256x256 kernel)
     float *d_foldv = nullptr, *d_headout = nullptr;
@@ -184,6 +186,7 @@ struct Engine {
     unsigned host_seq = 0, host_collected = 0;   // pipelined passes enqueued / collected
     unsigned host_redos = 0;                      // passes redone because a speculative window missed
     float margin = 0.75f;                         // speculative enlargement of the crop side
+    bool head_band_kernel = true;                 // false: the head as implicit GEMMs + head_out + decode (A/B, tests)
     int host_zero_copy = 0;                       // vt_config.host_zero_copy: 0 auto (single-stream engines), 1 always, -1 never
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
@@ -217,7 +220,7 @@ void Engine::destroy() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     void* devp[] = {d_blob, d_patches, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
-                    d_xh, d_xl, d_cstat, d_rstat, d_panel_cnt, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
+                    d_xh, d_xl, d_cstat, d_rstat, d_panel_cnt, d_band_cnt, d_band_best, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
                     d_results, d_stage};
     for (void* p : devp)
         if (p) (void)hipFree(p);
@@ -439,6 +442,8 @@ int Engine::alloc_buffers() {
     HIPCHK(dalloc0(&d_zeros, (size_t)128, stream));
     HIPCHK(dalloc0(&d_headout, Ms * 8, stream));
     HIPCHK(dalloc0(&d_states, (size_t)B, stream));
+    HIPCHK(dalloc0(&d_band_cnt, (size_t)B + 1, stream));
+    HIPCHK(dalloc0(&d_band_best, (size_t)B * d.gs * 2, stream));
     {   // B frame descriptors + the pass's PassOut behind them (one upload per pass)
         void* p = nullptr;
         HIPCHK(hipMalloc(&p, frames_block_bytes()));
@@ -595,37 +600,62 @@ int Engine::run_pass(Profiler* prof) {
                                       (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
                                       d.nt, d.ln_eps, stream);
     });
-    // centre head: 1x1 conv, three 3x3 convs (implicit GEMMs), then the f32 5-logit layer + decode
-    {
-        GemmArgs a{};
-        a.A = d_feat; a.lda = D; a.W = (const bf16_t*)find("head.w0")->ptr; a.ldw = D;
-        a.bias = (const float*)find("head.b0")->ptr;
-        a.M = Ms; a.N = d.C; a.K = D; a.Cb = d_ta; a.ldcb = d.C;
-        gemm(EPI_RELU_BF16, a);
-    }
+    // centre head: 1x1 conv, three 3x3 convs, then the f32 5-logit layer + decode. On the band kernel of
+    // k_head.hip (the A image of a band resident in LDS, logits + decode fused behind the last layer: 4 launches)
+    // where the shape allows it, else as implicit GEMMs on the 4-wave kernel + head_out + decode (6 launches).
+    DecodeArgs dec{};
+    dec.w4 = (const float*)find("head.w4")->ptr;
+    dec.b4 = (const float*)find("head.b4")->ptr;
+    dec.hann = (const float*)find("hann")->ptr;
+    dec.head_out = d_headout; dec.states = d_states; dec.results = d_results;
+    dec.out = (const PassOut*)(d_frames + B);
+    dec.B = B; dec.ns = d.ns; dec.grid = d.gs; dec.C = d.C;
+    dec.success_threshold = success_threshold;
+    const bool band = head_band_kernel && headconv_supported(d.gs, d.C, d.C, 9 * d.C, true) &&
+                      headconv_supported(d.gs, d.C, d.C, D, false);
     bf16_t* cur = d_ta;
     bf16_t* nxt = d_tb;
-    for (int k = 1; k <= 3; ++k) {     // 3x3 convs as implicit GEMMs: the im2col row is gathered by the A loads
-        GemmArgs a{};
-        const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
-        a.A = cur; a.lda = d.C; a.W = (const bf16_t*)find(wn)->ptr; a.ldw = 9 * d.C;
-        a.bias = (const float*)find(bn)->ptr;
-        a.M = Ms; a.N = d.C; a.K = 9 * d.C; a.Cb = nxt; a.ldcb = d.C;
-        a.conv_grid = d.gs; a.conv_C = d.C; a.zeros = d_zeros;
-        gemm(EPI_RELU_BF16, a);
-        std::swap(cur, nxt);
-    }
-    {
-        DecodeArgs a{};
-        a.t3 = cur;
-        a.w4 = (const float*)find("head.w4")->ptr;
-        a.b4 = (const float*)find("head.b4")->ptr;
-        a.hann = (const float*)find("hann")->ptr;
-        a.head_out = d_headout; a.states = d_states; a.results = d_results;
-        a.out = (const PassOut*)(d_frames + B);
-        a.B = B; a.ns = d.ns; a.grid = d.gs; a.C = d.C;
-        a.success_threshold = success_threshold;
-        L("decode", 2.0 * Ms * d.C * 5, (double)Ms * d.C * 2, [&] { return launch_decode(a, stream); });
+    if (band) {
+        HeadConvArgs h{};
+        h.in = d_feat; h.ldin = D; h.W = (const bf16_t*)find("head.w0")->ptr; h.ldw = D;
+        h.bias = (const float*)find("head.b0")->ptr; h.out = d_ta; h.ldout = d.C; h.zeros = d_zeros;
+        h.B = B; h.grid = d.gs; h.C = d.C; h.N = d.C; h.K = D; h.conv3x3 = 0;
+        L(prof ? "head_conv1x1" : "", 2.0 * Ms * d.C * D, 2.0 * ((double)Ms * D + (double)d.C * D + (double)Ms * d.C),
+          [&] { return launch_headconv(h, nullptr, stream); });
+        for (int k = 1; k <= 3; ++k) {
+            const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
+            HeadConvArgs c{};
+            c.in = cur; c.ldin = d.C; c.W = (const bf16_t*)find(wn)->ptr; c.ldw = 9 * d.C;
+            c.bias = (const float*)find(bn)->ptr; c.out = nxt; c.ldout = d.C; c.zeros = d_zeros;
+            c.B = B; c.grid = d.gs; c.C = d.C; c.N = d.C; c.K = 9 * d.C; c.conv3x3 = 1;
+            c.band_cnt = d_band_cnt; c.band_best = d_band_best;
+            const bool tail = k == 3;
+            const double fl = 2.0 * Ms * d.C * 9.0 * d.C + (tail ? 2.0 * Ms * d.C * 5 : 0.0);
+            const double by = 2.0 * (2.0 * Ms * d.C + 9.0 * d.C * d.C);
+            L(prof ? (tail ? "head_conv3x3_logits_decode" : "head_conv3x3") : "", fl, by,
+              [&] { return launch_headconv(c, tail ? &dec : nullptr, stream); });
+            std::swap(cur, nxt);
+        }
+    } else {
+        {
+            GemmArgs a{};
+            a.A = d_feat; a.lda = D; a.W = (const bf16_t*)find("head.w0")->ptr; a.ldw = D;
+            a.bias = (const float*)find("head.b0")->ptr;
+            a.M = Ms; a.N = d.C; a.K = D; a.Cb = d_ta; a.ldcb = d.C;
+            gemm(EPI_RELU_BF16, a);
+        }
+        for (int k = 1; k <= 3; ++k) {     // 3x3 convs as implicit GEMMs: the im2col row is gathered by the A loads
+            GemmArgs a{};
+            const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
+            a.A = cur; a.lda = d.C; a.W = (const bf16_t*)find(wn)->ptr; a.ldw = 9 * d.C;
+            a.bias = (const float*)find(bn)->ptr;
+            a.M = Ms; a.N = d.C; a.K = 9 * d.C; a.Cb = nxt; a.ldcb = d.C;
+            a.conv_grid = d.gs; a.conv_C = d.C; a.zeros = d_zeros;
+            gemm(EPI_RELU_BF16, a);
+            std::swap(cur, nxt);
+        }
+        dec.t3 = cur;
+        L("decode", 2.0 * Ms * d.C * 5, (double)Ms * d.C * 2, [&] { return launch_decode(dec, stream); });
     }
     if (lerr != hipSuccess)
         return set_err(VT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
@@ -799,7 +829,7 @@ static int make_engine(const char* path, const void* d_src, size_t bytes, int de
         return set_err(VT_ERR_INVALID_ARG, "n_streams %d out of range (1..%d)", B, VT_MAX_STREAMS);
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
-    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare()); HIPCHK(headconv_prepare());
     Engine* e = new (std::nothrow) Engine();
     if (!e) return set_err(VT_ERR_OOM, "out of host memory");
     e->device = device_id;
@@ -1148,6 +1178,21 @@ int vt_group_enable_taps(vt_group* g, int enable) try {
     if (enable && !e->d_taps)      // per slot: the hi and the lo half of the residual stream
         HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * 2 * e->B * e->d.ntok * e->d.D, e->stream));
     e->taps = enable != 0;
+    return VT_OK;
+} VT_NOTHROW_INT
+
+int vt_group_set_tuning(vt_group* g, const char* key, int value) try {
+    if (!g || !key) return set_err(VT_ERR_INVALID_ARG, "null argument");
+    Engine* e = g->e;
+    if (int rc = refuse_while_pipelined(e, "set_tuning")) return rc;
+    DEVICE_SCOPE(e->device);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const std::string k = key;
+    if (k == "head_band") e->head_band_kernel = value != 0;
+    else return set_err(VT_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+    // the captured pass holds the old choice: drop it, the next pass captures again
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     return VT_OK;
 } VT_NOTHROW_INT
 
@@ -1830,7 +1875,7 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
     if (N % 64 || K % 64) return set_err(VT_ERR_INVALID_ARG, "gemm: N and K must be multiples of 64");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
-    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare()); HIPCHK(headconv_prepare());
     const size_t MN = (size_t)M * N;
     DevBuf da, dw, db, dxh, dxl, dpos, dcb, dcs, drs, dcst, dro;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
@@ -1917,7 +1962,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     if (M <= 0 || N % 64 || K % 64 || iters < 1 || !us_out) return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
-    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare()); HIPCHK(headconv_prepare());
     const int D = N / 3, tokens = 4 * ((M + 3) / 4), npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dc, dcb, dvt, dxl, dcst, drs;
     HIPCHK(da.alloc((size_t)M * K * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
@@ -1996,7 +2041,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
-    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare());
+    HIPCHK(gemm_prepare()); HIPCHK(attention_prepare()); HIPCHK(headconv_prepare());
     const int M = B * tokens, H = D / 64, npad = (tokens + 63) / 64 * 64;
     DevBuf da, dw, db, dqk, dvt;
     HIPCHK(da.alloc((size_t)M * D * 2)); HIPCHK(dw.alloc((size_t)3 * D * D * 2)); HIPCHK(db.alloc((size_t)3 * D * 4));
@@ -2166,6 +2211,67 @@ int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w,
     std::vector<bf16_t> tmp(M * N);
     HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
+    return VT_OK;
+} VT_NOTHROW_INT
+
+// The head's band kernel (k_head.hip) on its own: out = relu(conv(t) + bias), conv3x3 != 0: t [B*grid*grid][Cin],
+// w [N][9*Cin], N == Cin; else the 1x1 layer: w [N][Cin]. R / ncb <= 0: the launcher's plan. t == NULL: operands
+// filled with a fixed pseudo-random pattern (timing runs). out (nullable): [B*grid*grid][N] bf16 values widened
+// to f32. iters > 0 and us_out: mean microseconds per launch over iters launches.
+int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
+                        int B, int grid, int Cin, int N, int conv3x3, int R, int ncb, int iters, float* us_out) try {
+    if (B < 1 || grid < 1 || Cin % 64 || N % 64 || (t && (!w || !bias)))
+        return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    const int K = conv3x3 ? 9 * Cin : Cin;
+    if (!headconv_supported(grid, conv3x3 ? Cin : N, N, K, conv3x3 != 0))
+        return set_err(VT_ERR_INVALID_ARG, "shape not supported by the band kernel");
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    HIPCHK(headconv_prepare());
+    const size_t M = (size_t)B * grid * grid;
+    DevBuf dt, dw, db, dout, dz;
+    HIPCHK(dt.alloc(M * Cin * 2)); HIPCHK(dw.alloc((size_t)N * K * 2)); HIPCHK(db.alloc((size_t)N * 4));
+    HIPCHK(dout.alloc(M * N * 2)); HIPCHK(dz.alloc(256));
+    if (t) {
+        HIPCHK(hipMemcpy(dt.p, t, M * Cin * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<bf16_t> ht(M * Cin), hw((size_t)N * K);
+        uint32_t seed = 777u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (bf16_t)(0x3c00u + ((seed >> 9) & 0x3ffu) + ((seed >> 3) & 0x8000u)); };
+        for (auto& v : ht) v = rnd();
+        for (auto& v : hw) v = rnd();
+        HIPCHK(hipMemcpy(dt.p, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(db.p, 0, (size_t)N * 4));
+    }
+    HIPCHK(hipMemset(dz.p, 0, 256));
+    HeadConvArgs h{};
+    h.in = (const bf16_t*)dt.p; h.ldin = Cin; h.W = (const bf16_t*)dw.p; h.ldw = K; h.bias = (const float*)db.p;
+    h.out = (bf16_t*)dout.p; h.ldout = N; h.zeros = (const bf16_t*)dz.p;
+    h.B = B; h.grid = grid; h.C = conv3x3 ? Cin : N; h.N = N; h.K = K; h.conv3x3 = conv3x3 ? 1 : 0;
+    h.R = R; h.ncb = ncb;
+    HIPCHK(launch_headconv(h, nullptr, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    if (out) {
+        std::vector<bf16_t> tmp(M * N);
+        HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
+    }
+    if (iters > 0 && us_out) {
+        for (int i = 0; i < 3; ++i) HIPCHK(launch_headconv(h, nullptr, nullptr));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) HIPCHK(launch_headconv(h, nullptr, nullptr));
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *us_out = ms * 1000.0f / iters;
+    }
     return VT_OK;
 } VT_NOTHROW_INT
 

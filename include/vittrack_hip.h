@@ -357,6 +357,11 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
 /* Stage taps: when enabled the pass runs eagerly and keeps a copy of the residual stream after the
  * patch embedding and after every encoder block (for stage-level parity tests). */
 int vt_group_enable_taps(vt_group* g, int enable);
+/* Diagnostics (A/B measurements and parity tests of alternative kernels; results are the same quantity either
+ * way): key "head_band": 1 (default) = the head's convolutions on the band kernel with the logits and the decode
+ * fused behind the last layer, 0 = implicit GEMMs + head_out + decode launches. Not while a pipelined pass is
+ * outstanding. */
+int vt_group_set_tuning(vt_group* g, const char* key, int value);
 /* A single tracker viewed as a group of one (taps, profiling, stream handle). The view belongs to
  * the tracker: valid until vt_destroy(t), the same pointer on every call, never to be destroyed
  * by the caller. */
@@ -406,6 +411,13 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
  * out [B*grid*grid][N] (bf16 widened to f32). C % 64 == 0, N % 64 == 0; cfg 0..6 (4..6: C % 128 == 0), < 0: launcher's choice. */
 int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias,
                             float* out, int B, int grid, int C, int N, int cfg);
+/* The head's band kernel (csrc/k_head.hip) on its own: out = relu(conv(t) + bias). conv3x3 != 0: t [B*grid*grid][Cin],
+ * w [N][9*Cin] (column (ky*3+kx)*Cin + c), N == Cin, zero padding; else the 1x1 layer, w [N][Cin]. R (rows of the
+ * map per workgroup) / ncb (16-column blocks per wave) <= 0: the launcher's plan. t == NULL: operands filled with a
+ * fixed pseudo-random pattern (timing runs). out (nullable): bf16 values widened to f32. iters > 0 and us_out: mean
+ * microseconds per launch. */
+int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
+                        int B, int grid, int Cin, int N, int conv3x3, int R, int ncb, int iters, float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
  * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;

@@ -242,7 +242,7 @@ def test_attention(gpu, B, N, H, scale, mode):
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
                                          (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
                                          (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
-@pytest.mark.parametrize("mode", [3, 6])
+@pytest.mark.parametrize("mode", [3, 6, 8, 9])
 def test_attention_mode3(gpu, B, N, H, scale, mode):
     """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
     Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
@@ -262,7 +262,7 @@ def test_attention_mode3(gpu, B, N, H, scale, mode):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
     sequence: the reference must move and everything accumulated before be rescaled (mode 3: the
@@ -283,7 +283,7 @@ def test_attention_late_maximum_rescale(gpu, mode):
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("level", [-20.0, -50.0, -64.0, -150.0, 55.0, 90.0])
 def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
@@ -330,7 +330,7 @@ def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
@@ -385,6 +385,66 @@ def test_head_conv3x3_as_implicit_gemm(gpu, B, grid, C, N, cfg):
                               gpu.weights.f32_to_bf16_bits(w.reshape(N, 9 * C)), bias, B, grid, cfg=cfg)
     expect = gpu.weights.bf16_bits_to_f32(gpu.weights.f32_to_bf16_bits(ref.astype(np.float32)))
     assert np.array_equal(got, expect)
+
+
+def _conv3x3_ref(t, w, bias):
+    B, grid, _, C = t.shape
+    N = w.shape[0]
+    pad = np.zeros((B, grid + 2, grid + 2, C), np.float32)
+    pad[:, 1:-1, 1:-1] = t
+    ref = np.zeros((B, grid, grid, N), np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            ref += pad[:, ky:ky + grid, kx:kx + grid].reshape(-1, C).astype(np.float64).dot(
+                w[:, ky, kx].T.astype(np.float64)).reshape(B, grid, grid, N)
+    return np.maximum(ref + bias, 0).reshape(-1, N)
+
+
+@pytest.mark.parametrize("B,grid,C,R,ncb", [(1, 24, 128, 0, 0), (1, 24, 128, 1, 1), (1, 24, 128, 1, 2), (2, 24, 128, 3, 2),
+                                            (3, 24, 128, 4, 2), (2, 24, 128, 4, 1), (30, 24, 128, 0, 0), (2, 16, 128, 4, 2),
+                                            (2, 16, 128, 7, 1), (2, 28, 128, 4, 2), (1, 28, 128, 3, 2), (3, 8, 64, 0, 0),
+                                            (2, 8, 64, 3, 1), (1, 8, 64, 8, 1), (2, 5, 64, 2, 1)])
+def test_head_band_kernel_conv3x3(gpu, B, grid, C, R, ncb):
+    """k_head.hip, 3x3 layers: the band's input cells + halo resident in LDS, nine taps as shifted views. Exact small
+    integers against a direct NumPy convolution with zero padding - every band height incl. ragged last bands (24 = 5 *
+    4 + 4, 16 = 2 * 7 + 2, 5 = 2 * 2 + 1), half and full column groups, maps whose bands do not fill their last block of 16 cells,
+    the launcher's own plan at one stream and at the benchmark's 30; and on random bf16 data bit-identical to the
+    implicit-GEMM kernel (the same accumulation chain over k = tap * C + c)."""
+    rng = np.random.default_rng(B * 1000 + grid * 10 + C + R)
+    t = rng.integers(-3, 4, size=(B, grid, grid, C)).astype(np.float32)
+    w = rng.integers(-2, 3, size=(C, 3, 3, C)).astype(np.float32)
+    bias = rng.integers(-4, 5, size=C).astype(np.float32)
+    tb, wb = gpu.weights.f32_to_bf16_bits(t.reshape(-1, C)), gpu.weights.f32_to_bf16_bits(w.reshape(C, 9 * C))
+    expect = gpu.weights.bf16_bits_to_f32(gpu.weights.f32_to_bf16_bits(_conv3x3_ref(t, w, bias).astype(np.float32)))
+    for _ in range(2):
+        assert np.array_equal(gpu.op_headconv(tb, wb, bias, B, grid, True, R, ncb), expect)
+    tr, _ = _rand_bf16(gpu, rng, (B * grid * grid, C))
+    wr, _ = _rand_bf16(gpu, rng, (C, 9 * C), 0.05)
+    br = rng.standard_normal(C).astype(np.float32)
+    assert np.array_equal(gpu.op_headconv(tr, wr, br, B, grid, True, R, ncb),
+                          gpu.op_conv3x3_relu(tr, wr, br, B, grid, cfg=2))
+
+
+@pytest.mark.parametrize("B,grid,K,N,R,ncb", [(1, 24, 768, 128, 0, 0), (2, 24, 768, 128, 3, 2), (2, 24, 768, 128, 1, 1),
+                                              (30, 24, 768, 128, 0, 0), (2, 28, 1024, 128, 4, 2), (2, 16, 768, 128, 5, 1),
+                                              (3, 8, 128, 64, 0, 0), (2, 8, 128, 64, 3, 1), (2, 24, 64, 128, 2, 2)])
+def test_head_band_kernel_conv1x1(gpu, B, grid, K, N, R, ncb):
+    """k_head.hip, the 1x1 layer (K = D): A rows of the band stream through the ring beside the weights (K-tile depth 64,
+    odd numbers of row blocks padded to even). Exact integers, and random data bit-identical to the 4-wave GEMM kernel's
+    ReLU epilogue."""
+    rng = np.random.default_rng(B + grid + K + N + R)
+    M = B * grid * grid
+    a = rng.integers(-3, 4, size=(M, K)).astype(np.float32)
+    w = rng.integers(-3, 4, size=(N, K)).astype(np.float32)
+    bias = rng.integers(-8, 9, size=N).astype(np.float32)
+    ref = bf16_round(np.maximum(a @ w.T + bias, 0))
+    for _ in range(2):
+        assert np.array_equal(gpu.op_headconv(_bits(gpu, a), _bits(gpu, w), bias, B, grid, False, R, ncb), ref)
+    ar, _ = _rand_bf16(gpu, rng, (M, K))
+    wr, _ = _rand_bf16(gpu, rng, (N, K), 0.05)
+    br = rng.standard_normal(N).astype(np.float32)
+    assert np.array_equal(gpu.op_headconv(ar, wr, br, B, grid, False, R, ncb),
+                          gpu.op_gemm_bf16(ar, wr, br, epilogue=3, cfg=2))
 
 
 @pytest.mark.parametrize("tokens,B", [(720, 30), (980, 9), (100, 70)])

@@ -851,3 +851,36 @@ def test_zero_copy_sees_a_registered_buffer_rewritten_in_place(gpu, weights_tiny
     assert got[0] == want[0], "single tracker: stale pixels from a rewritten registered buffer"
     assert got[1] == want[1], "synchronous group"
     assert got[2] == want[2], "pipelined group"
+
+
+@pytest.mark.parametrize("cfg,B", [("tiny", 1), ("tiny", 5), ("cfg3", 1), ("cfg3", 7), ("cfg2", 3)])
+def test_head_band_kernel_equals_the_separate_launches(gpu, cfg, B):
+    """the head on the band kernel (k_head.hip: 4 launches, logits + decode fused behind the last 3x3 layer, the last
+    band of a stream to arrive decodes it) against the same engine with the head as implicit GEMMs + head_out +
+    decode launches (vt_group_set_tuning "head_band" 0): the last feature map bit-identical, the logits equal up to
+    the f32 summation order of the 5-logit layer, identical boxes and success flags over a short closed loop; graph
+    replay and eager."""
+    name = {"tiny": "tiny", "cfg3": "vitb16_t192_s384", "cfg2": "vitb16_t128_s256"}[cfg]
+    weights = gpu.weights.ensure_weights(name)
+    w, h = (640, 480) if cfg == "tiny" else (1920, 1080)
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=41)
+    for use_graph in (True, False):
+        ga = gpu.Group(weights, n_streams=B, use_graph=use_graph)
+        gb = gpu.Group(weights, n_streams=B, use_graph=use_graph)
+        gb.set_tuning("head_band", 0)
+        f0 = gpu.NV12Frame(sc.frame_nv12(0), w, h)
+        for i in range(B):
+            ga.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+            gb.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+        for t in range(6):
+            f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+            ra, rb = ga.update_host([f] * B), gb.update_host([f] * B)
+            assert [(r.bbox, r.success) for r in ra] == [(r.bbox, r.success) for r in rb], t
+            assert max(abs(x.score - y.score) for x, y in zip(ra, rb)) < 1e-5
+            for i in (0, B - 1):
+                assert np.array_equal(ga.read_tensor("head_t3", i), gb.read_tensor("head_t3", i))
+                ha, hb = ga.read_tensor("head_out", i), gb.read_tensor("head_out", i)
+                assert np.abs(ha - hb).max() <= 1e-5 * max(1.0, np.abs(hb).max())
+        sa, sb = ga.read_state(B - 1), gb.read_state(B - 1)
+        assert sa["frames_done"] == sb["frames_done"] == 6 and sa["last_idx"] == sb["last_idx"]
+        del ga, gb

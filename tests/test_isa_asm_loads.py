@@ -127,6 +127,7 @@ def _check_function(name, body):
 @pytest.mark.parametrize("source,pattern,at_least", [
     ("k_gemm.hip", r"gemm_bf16_kernel", 10),     # 64x64 X-epilogues + every bf16 epilogue with a folded LayerNorm
     ("k_gemm256.hip", r"gemm256p?_kernel", 2),   # the last-arriver finalize of the X-epilogues' row terms
+    ("k_head.hip", r"head_conv_kernel", 14),     # fused tail: the stream state prefetched by thread 0, sc1 hand-off loads
 ])
 def test_asm_load_destinations_are_untouched_until_their_wait(source, pattern, at_least):
     isa = _isa_of(source)
