@@ -312,7 +312,16 @@ __global__ __launch_bounds__(256) void preproc_wide_kernel(const FrameDesc* __re
 // before), kept in LDS as r | g << 8 | b << 16 | miss << 24, and the lanes interpolate from LDS. A
 // tap that lay outside the stored window still raises window_miss only if an output pixel uses it.
 // Same arithmetic, same order: bit-exact with the other kernels and the oracle. Rectangles that do
-// not fit the 16 KiB buffer (very large targets) take the direct fetches of the wide kernel.
+// not fit the 16 KiB buffer take the direct fetches of the wide kernel: that is every tile from a scale of 2
+// source pixels per output pixel, i.e. targets from ~130 px at search 384 and ~90 px at search 256 - ordinary
+// sizes at 1080p, and a cliff: 30 streams, 1080p, by target size (profiles/r05_preproc_by_target.txt): search 384:
+// 64 px 18.6 us, 128 px 25.2, 160 px 92.6, 256 px 83.6; search 256: 64 px 13.5, 96 px and larger 39-40 (2-4 % of a
+// pass instead of 0.4 %). Round 5 staged such rectangles in 2 or 4 horizontal strips of the tile (bit-exact; cfg3
+// 160 px 35 us, cfg2 96 px 23 us) - but every form of the strip loop tried (inside the body, as an outer loop over
+// opaque passes, with the 8-pixel run in halves) left hipcc at 76-99 VGPRs and 20 spilled SGPRs where this kernel
+// has 62: six or five blocks per CU instead of eight, + 3.8 us on the 64-px benchmark target, so it was not
+// shipped. What would: two captured graphs per engine (16-KiB and 64-KiB buffer), chosen per pass from the boxes
+// the host already knows.
 #define PRE_TILE_W 64
 #define PRE_TILE_H 32
 // 16 KiB of LDS per block: eight 256-thread blocks per CU (the thread limit), so the 2,160 blocks of a
@@ -431,7 +440,8 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     bf16_t* row = patches + ((size_t)b * ntok + row_off + token) * kpad;
     int miss = 0;
     if (!staged) {
-        // rare (targets of several hundred pixels): direct fetches, pixel by pixel, 2-byte stores. Kept out of
+        // rectangles over 4,096 source pixels (targets from ~130 px at search 384, ~90 px at search 256: see the
+        // kernel's header): direct fetches, pixel by pixel, 2-byte stores. Kept out of
         // the staged path's code: inlined into its unrolled loop the 32 fetch_rgb bodies cost 70 VGPRs and
         // with them a block per CU.
 #pragma unroll 1
