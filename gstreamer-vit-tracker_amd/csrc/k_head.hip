@@ -368,16 +368,38 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
         for (int s_ = 0; s_ < NS - 1; ++s_)
             if (s_ < ntile) issue_tile(s_, s_);
         int cur = 0;
+#ifdef VT_STAMPS
+        unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#define HSTAMP(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define HSTAMP(v)
+#endif
         for (int kt = 0; kt < ntile; ++kt) {
+            HSTAMP(st_a)
             const int ahead = min(NS - 2, ntile - 1 - kt);       // tiles that may stay in flight behind tile kt
             if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * IPS>();
             else if (ahead >= 1) wait_vmcnt<IPS>();
             else wait_vmcnt<0>();
+#ifdef VT_STAMPS
+            HSTAMP(st_b) st_wait += st_b - st_a;
+#endif
             __builtin_amdgcn_s_barrier();           // tile kt has landed; the computing waves are done with tile kt - 1
             __builtin_amdgcn_sched_barrier(0);
+#ifdef VT_STAMPS
+            HSTAMP(st_a) st_bar += st_a - st_b;
+#endif
             if (kt + NS - 1 < ntile) issue_tile(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+#ifdef VT_STAMPS
+            HSTAMP(st_b) st_issue += st_b - st_a;
+#endif
             cur = (cur + 1 == NS) ? 0 : cur + 1;
         }
+#ifdef VT_STAMPS
+        if (p.dbg && lane == 0) {
+            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+            d[0] = st_wait; d[1] = st_bar; d[2] = st_issue; d[3] = __builtin_amdgcn_s_memtime() - st_t0;
+        }
+#endif
     } else {
         // ---- computing waves -------------------------------------------------------------------------------------
         // fragment addresses. W rows of this wave: wave * 16 * NCB + j * 16 + l15
@@ -402,9 +424,16 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             }
         }
         int cur = 0;
+#ifdef VT_STAMPS
+        unsigned long long st_bar = 0, st_comp = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#endif
         for (int kt = 0; kt < ntile; ++kt) {
+            HSTAMP(st_a)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef VT_STAMPS
+            HSTAMP(st_b) st_bar += st_b - st_a;
+#endif
             const char* st = ring + cur * stage;
             int aoff[MB], asw[MB];
             if constexpr (HALO) {
@@ -432,6 +461,12 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             for (int j = 0; j < NCB; ++j) wf[0][j] = *reinterpret_cast<const bf16x8_t*>(st + woff[j] + ((lq ^ wsw[j]) << 4));
 #pragma unroll
             for (int i = 0; i < MB; ++i) af[0][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((lq ^ asw[i]) << 4));
+            // The read block and the MFMA block of a k-step are fenced for the scheduler: left alone hipcc interleaved the
+            // reads among the MFMAs with an lgkmcnt(0) in front of every pair of MFMAs - each wait exposed a full LDS round
+            // trip to the one wave of the SIMD (in-kernel stamps: 13.9 k cycles of compute for 5.8 k cycles of MFMAs per
+            // band, the loaders idle at the barrier). Fenced, the reads of step ks + 1 are all in flight before the first
+            // MFMA of step ks, which waits with a counted lgkmcnt for step ks's fragments only.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cb = ks & 1, nb = cb ^ 1;
@@ -444,14 +479,25 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
                     for (int i = 0; i < MB; ++i)
                         af[nb][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((ch ^ asw[i]) << 4));
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NCB; ++j)   // D[n][m]: rows = output channels (registers), columns = cells (lanes)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef VT_STAMPS
+            HSTAMP(st_a) st_comp += st_a - st_b;
+#endif
             cur = (cur + 1 == NS) ? 0 : cur + 1;
         }
+#ifdef VT_STAMPS
+        if (p.dbg && lane == 0) {
+            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+            d[0] = 0; d[1] = st_bar; d[2] = st_comp; d[3] = __builtin_amdgcn_s_memtime() - st_t0;
+        }
+#endif
     }
     __syncthreads();                               // every wave is done with the ring (no LDS-DMA outstanding)
     // TAIL: the stream's state and the pass's output addresses, for the workgroup that will turn out to be the stream's

@@ -207,6 +207,7 @@ struct HeadConvArgs {
     unsigned* band_cnt;         // fused tail only: [B] arrival counters, zero between launches
     float* band_best;           // fused tail only: [B][bands][2] each band's argmax candidate (response, cell), bands <= grid
     int bands, mbe_max;         // filled in by the launcher
+    unsigned long long* dbg;    // diagnostic builds only (VT_STAMPS): per-wave cycle sums [wgs][8][4]
 };
 bool headconv_supported(int grid, int C, int N, int K, bool conv3x3);
 hipError_t headconv_prepare();     // once per device, before the first launch / any stream capture

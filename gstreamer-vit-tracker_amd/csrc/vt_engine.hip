@@ -2259,6 +2259,13 @@ int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, con
         HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
     }
+#ifdef VT_STAMPS   // diagnostic builds only: per-wave cycle sums of the main loop, medians printed
+    DevBuf ddbg;
+    const size_t dbg_words = (size_t)B * grid * 2 * 8 * 4;
+    HIPCHK(ddbg.alloc(dbg_words * 8));
+    HIPCHK(hipMemset(ddbg.p, 0, dbg_words * 8));
+    h.dbg = (unsigned long long*)ddbg.p;
+#endif
     if (iters > 0 && us_out) {
         for (int i = 0; i < 3; ++i) HIPCHK(launch_headconv(h, nullptr, nullptr));
         hipEvent_t e0, e1;
@@ -2272,6 +2279,23 @@ int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, con
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *us_out = ms * 1000.0f / iters;
     }
+#ifdef VT_STAMPS
+    {
+        std::vector<unsigned long long> hd(dbg_words);
+        HIPCHK(hipMemcpy(hd.data(), ddbg.p, dbg_words * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> col[2][4];
+        for (size_t wg = 0; wg < dbg_words / 32; ++wg)
+            for (int wv = 0; wv < 8; ++wv) {
+                const unsigned long long* d = &hd[(wg * 8 + wv) * 4];
+                if (d[3] == 0) continue;
+                for (int k = 0; k < 4; ++k) col[wv >= 4][k].push_back(d[k]);
+            }
+        auto med = [](std::vector<unsigned long long>& v) { if (v.empty()) return 0ull; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        fprintf(stderr, "headconv stamps (median cycles per wave over the main loop): computing waves [-, barrier, compute, total] = "
+                "%llu %llu %llu %llu; loader waves [vmcnt wait, barrier, issue, total] = %llu %llu %llu %llu\n",
+                med(col[0][0]), med(col[0][1]), med(col[0][2]), med(col[0][3]), med(col[1][0]), med(col[1][1]), med(col[1][2]), med(col[1][3]));
+    }
+#endif
     return VT_OK;
 } VT_NOTHROW_INT
 
