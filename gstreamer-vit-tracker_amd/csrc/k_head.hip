@@ -264,7 +264,20 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
     constexpr int WPW = BN / RPP / 4;             // W pieces per loader wave and stage
     static_assert(BK == 64 || BK == 128, "K-tile depth");
     static_assert(!TAIL || HALO, "the fused tail follows a 3x3 layer");
-    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : row & 15; };
+    // LDS images: rows of ROWB bytes, 16-B chunk c of a row stored at chunk slot slot_of(c, key) (LDS-DMA writes lane-
+    // linear, so the permutation is applied to the per-lane SOURCE chunk - chunk_at - and again on the read).
+    // 128-B rows (two per bank line): slot = c ^ key with key = row >> 1 - the 4-wave GEMM's swizzle, conflict-free for the
+    // ds_read_b128 lane groups when a group's 16 rows start at a multiple of 16.
+    // 256-B rows (one bank line each): the lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) mix two k-chunks - 8
+    // lanes read chunk c, 8 read chunk c ^ 1 - of 16 CONSECUTIVE rows that start ANYWHERE here (the 3x3 taps shift the
+    // window cell by cell). slot = (c & 1) * 8 + (((c >> 1) ^ key) & 7): the chunk's low bit picks the half of the line,
+    // so the two sets of lanes never meet, and within a half 8 consecutive keys give 8 distinct slots whatever the start
+    // (the first version, c ^ (row & 15), was 2-way on every odd start and at every wrap of a map row: PMC 31 % of the
+    // LDS cycles of a 3x3 layer were bank conflicts). key of an A-image cell = its UNPADDED map index, which stays
+    // consecutive across the ends of the map's rows; of a weight row its index.
+    auto slot_of = [](int c, int key) { return BK == 64 ? (c ^ key) & 7 : ((c & 1) << 3) | (((c >> 1) ^ key) & 7); };
+    auto chunk_at = [](int slot, int key) { return BK == 64 ? (slot ^ key) & 7 : ((((slot & 7) ^ key) & 7) << 1) | (slot >> 3); };
+    auto key_of_row = [](int row) { return BK == 64 ? row >> 1 : row; };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;                // wave-uniform
@@ -331,9 +344,10 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             const int npieces = himg / 1024;
             for (int pc = w4; pc < npieces; pc += 4) {
                 const int h = pc * RPP + lane / CPR;                 // halo cell of this lane
-                const int c = (lane % CPR) ^ swz(h);                 // global chunk that lands in LDS chunk slot lane % CPR
                 const int hy = h / hw, hx = h - hy * hw;
                 const int y = y0 + hy - 1, x = hx - 1;
+                const int key = BK == 64 ? h >> 1 : y * grid + x;     // 256-B rows: the cell's unpadded map index
+                const int c = chunk_at(lane % CPR, key);             // global chunk that lands in LDS chunk slot lane % CPR
                 const bool in = h < hcells && y >= 0 && y < grid && x >= 0 && x < grid;
                 const bf16_t* src = in ? p.in + ((size_t)(b * ns + y * grid + x)) * p.ldin + c * 8 : p.zeros + c * 8;
                 glds16(src, smem + pc * 1024);
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
             const int row = (w4 * WPW + j) * RPP + lane / CPR;
-            const int c = (lane % CPR) ^ swz(row);
+            const int c = chunk_at(lane % CPR, key_of_row(row));
             wsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
         }
         const bf16_t* asrc[APW + 1];
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 #pragma unroll
             for (int j = 0; j < APW; ++j) {
                 const int row = (w4 * APW + j) * RPP + lane / CPR;
-                const int c = (lane % CPR) ^ swz(row);
+                const int c = chunk_at(lane % CPR, key_of_row(row));
                 const int rc = row < cells ? row : cells - 1;        // padding rows repeat the last cell, never stored
                 asrc[j] = p.in + (size_t)(m_base + rc) * p.ldin + c * 8;
             }
@@ -408,10 +422,11 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
         for (int j = 0; j < NCB; ++j) {
             const int row = w4 * 16 * NCB + j * 16 + l15;
             woff[j] = a_stage + row * ROWB;
-            wsw[j] = swz(row);
+            wsw[j] = key_of_row(row);
         }
         // A rows: cell i * 16 + l15 of the band (padding rows use the band's last cell)
         int h0[MB];                                    // HALO: halo index of the cell's tap (0, 0); else LDS row
+        int cm[MB];                                    // HALO: unpadded map index of the cell's tap (0, 0) (swizzle key)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             int cell = i * 16 + l15;
@@ -419,8 +434,10 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             if constexpr (HALO) {
                 const int y = cell / grid, x = cell - y * grid;
                 h0[i] = y * hw + x;
+                cm[i] = (y0 + y - 1) * grid + x - 1;
             } else {
                 h0[i] = i * 16 + l15;
+                cm[i] = 0;
             }
         }
         int cur = 0;
@@ -434,33 +451,36 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 #ifdef VT_STAMPS
             HSTAMP(st_b) st_bar += st_b - st_a;
 #endif
-            const char* st = ring + cur * stage;
-            int aoff[MB], asw[MB];
+            // fragment addresses of the tap's first k-step: LDS byte offset of chunk lq of each row. The chunk of k-step
+            // ks is 4 ks + lq, and in both swizzles that moves the slot by an XOR of bits that lq and the key do not carry
+            // (256-B rows: slot ^ 2 ks, 128-B rows: slot ^ 4 ks): one v_xor per address and k-step instead of the whole
+            // swizzle (3 VALU ops each - with one wave per SIMD they are issued between the MFMAs, not beside them: 16 of
+            // them and 7 LDS reads per 10 MFMAs made a k-step 333 cycles for 160 of matrix pipe).
+            const uint32_t sbase = (uint32_t)(himg + cur * stage);           // this stage, as an offset into smem
+            uint32_t a0[MB], w0[NCB];
             if constexpr (HALO) {
                 const int ky = kt / 3, kx = kt - 3 * ky;
-                const int toff = ky * hw + kx;
+                const int toff = ky * hw + kx, koff = ky * grid + kx;
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
                     const int h = h0[i] + toff;
-                    aoff[i] = h * ROWB;
-                    asw[i] = swz(h);
+                    a0[i] = (uint32_t)(h * ROWB + (slot_of(lq, BK == 64 ? h >> 1 : cm[i] + koff) << 4));
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    aoff[i] = h0[i] * ROWB;
-                    asw[i] = swz(h0[i]);
-                }
+                for (int i = 0; i < MB; ++i) a0[i] = sbase + (uint32_t)(h0[i] * ROWB + (slot_of(lq, key_of_row(h0[i])) << 4));
             }
-            const char* abase = HALO ? smem : st;
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) w0[j] = sbase + (uint32_t)(woff[j] + (slot_of(lq, wsw[j]) << 4));
             constexpr int KS = BK / 32;
+            constexpr uint32_t KSX = BK == 64 ? 64u : 32u;       // byte-offset XOR per k-step
             // k-steps software-pipelined inside the wave (one computing wave per SIMD: nobody else hides an LDS round
             // trip): the fragments of step ks + 1 are read while the MFMAs of step ks issue
             bf16x8_t wf[2][NCB], af[2][MB];
 #pragma unroll
-            for (int j = 0; j < NCB; ++j) wf[0][j] = *reinterpret_cast<const bf16x8_t*>(st + woff[j] + ((lq ^ wsw[j]) << 4));
+            for (int j = 0; j < NCB; ++j) wf[0][j] = *reinterpret_cast<const bf16x8_t*>(smem + w0[j]);
 #pragma unroll
-            for (int i = 0; i < MB; ++i) af[0][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((lq ^ asw[i]) << 4));
+            for (int i = 0; i < MB; ++i) af[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + a0[i]);
             // The read block and the MFMA block of a k-step are fenced for the scheduler: left alone hipcc interleaved the
             // reads among the MFMAs with an lgkmcnt(0) in front of every pair of MFMAs - each wait exposed a full LDS round
             // trip to the one wave of the SIMD (in-kernel stamps: 13.9 k cycles of compute for 5.8 k cycles of MFMAs per
@@ -471,13 +491,12 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             for (int ks = 0; ks < KS; ++ks) {
                 const int cb = ks & 1, nb = cb ^ 1;
                 if (ks + 1 < KS) {
-                    const int ch = (ks + 1) * 4 + lq;
 #pragma unroll
                     for (int j = 0; j < NCB; ++j)
-                        wf[nb][j] = *reinterpret_cast<const bf16x8_t*>(st + woff[j] + ((ch ^ wsw[j]) << 4));
+                        wf[nb][j] = *reinterpret_cast<const bf16x8_t*>(smem + (w0[j] ^ ((ks + 1) * KSX)));
 #pragma unroll
                     for (int i = 0; i < MB; ++i)
-                        af[nb][i] = *reinterpret_cast<const bf16x8_t*>(abase + aoff[i] + ((ch ^ asw[i]) << 4));
+                        af[nb][i] = *reinterpret_cast<const bf16x8_t*>(smem + (a0[i] ^ ((ks + 1) * KSX)));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
