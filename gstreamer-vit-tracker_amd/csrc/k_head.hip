@@ -72,8 +72,9 @@ __device__ __forceinline__ void decode_box(const DecodeArgs& a, int b, int idx, 
         float t[5] = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (ix >= 0 && iy >= 0 && ix < grid && iy < grid) {
             float o[5];
+            const float hv = a.hann[iy * grid + ix];       // issued ahead of the logits' loads, not behind their wait
             load_logits<SC1>(a.head_out + ((size_t)b * ns + iy * grid + ix) * 8, o);
-            const float r = hc_sigmoid(o[0]) * a.hann[iy * grid + ix];
+            const float r = hc_sigmoid(o[0]) * hv;
             const float w = r * r;
             const float offx = 3.0f * hc_sigmoid(o[1]) - 1.0f;
             const float offy = 3.0f * hc_sigmoid(o[2]) - 1.0f;
