@@ -440,7 +440,7 @@ def run_rank(args):
         # (rocprofv3 --pmc is a separate run, one counter group per pass), so the number comes from the
         # committed summary of those passes on the same kernel and shape, with its provenance
         traffic, traffic_src = None, None
-        for pmc_name in ("r04_dominant_kernel_pmc.json", "r03_dominant_kernel_pmc.json"):
+        for pmc_name in ("r05_dominant_kernel_pmc.json", "r04_dominant_kernel_pmc.json", "r03_dominant_kernel_pmc.json"):
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
             if traffic is None and os.path.exists(pmc_path):
                 try:
