@@ -316,19 +316,27 @@ __global__ __launch_bounds__(256) void preproc_wide_kernel(const FrameDesc* __re
 // source pixels per output pixel, i.e. targets from ~130 px at search 384 and ~90 px at search 256 - ordinary
 // sizes at 1080p, and a cliff: 30 streams, 1080p, by target size (profiles/r05_preproc_by_target.txt): search 384:
 // 64 px 18.6 us, 128 px 25.2, 160 px 92.6, 256 px 83.6; search 256: 64 px 13.5, 96 px and larger 39-40 (2-4 % of a
-// pass instead of 0.4 %). Round 5 staged such rectangles in 2 or 4 horizontal strips of the tile (bit-exact; cfg3
-// 160 px 35 us, cfg2 96 px 23 us) - but every form of the strip loop tried (inside the body, as an outer loop over
-// opaque passes, with the 8-pixel run in halves) left hipcc at 76-99 VGPRs and 20 spilled SGPRs where this kernel
-// has 62: six or five blocks per CU instead of eight, + 3.8 us on the 64-px benchmark target, so it was not
-// shipped. What would: two captured graphs per engine (16-KiB and 64-KiB buffer), chosen per pass from the boxes
-// the host already knows.
+// pass instead of 0.4 %). Round 5, first attempt: such rectangles staged in 2 or 4 horizontal strips of the tile
+// (bit-exact; cfg3 160 px 35 us, cfg2 96 px 23 us) - but every form of the strip loop tried (inside the body, as an
+// outer loop over opaque passes, with the 8-pixel run in halves) left hipcc at 76-99 VGPRs and 20 spilled SGPRs
+// where this kernel has 62: six or five blocks per CU instead of eight, + 3.8 us on the 64-px benchmark target; not
+// shipped. What shipped: the kernel in three buffer tiers (below), one captured graph each, chosen per pass by the
+// engine from the boxes the host already knows: 160 px at cfg3 29.5 us, 96 px at cfg2 19.5 us, the 64-px case on
+// the unchanged tier-0 kernel.
 #define PRE_TILE_W 64
 #define PRE_TILE_H 32
 // 16 KiB of LDS per block: eight 256-thread blocks per CU (the thread limit), so the 2,160 blocks of a
 // 30-stream pass are resident at once - a block is one dependent chain (descriptor -> state -> fetch -> LDS ->
 // interpolate -> store, ~7 us) and with 32 KiB (5 blocks per CU) the pass took two rounds of it. A 64-px target
 // at 1080p needs ~1,000 source pixels per tile, a 128-px one ~3,900.
-#define PRE_TILE_LDS 4096       // source pixels (16 KiB)
+#define PRE_TILE_LDS 4096       // source pixels (16 KiB): tier 0, the benchmark's 64-px targets
+// Round 5 - larger buffers for larger targets, chosen PER LAUNCH by the engine from the boxes the host already knows
+// (vt_engine.hip: one captured graph per tier): tier 1 = 8,192 pixels (32 KiB, five blocks per CU: scales up to ~1.9
+// source pixels per output pixel, targets up to ~185 px at search 384 / ~120 px at search 256), tier 2 = 16,384 pixels
+// (64 KiB, two blocks per CU: scales up to ~2.75, ~260 / ~175 px). A tile that still does not fit takes the per-pixel
+// path below - correct at any size, a 3-4x cliff in time (profiles/r05_preproc_by_target.txt) that tier 0 alone hit
+// from ~130-px targets. The tier changes which path a tile takes, never a value: every path is bit-exact.
+template <int LDSPX>
 __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __restrict__ frames,
                                                            StreamState* __restrict__ states,
                                                            bf16_t* __restrict__ patches, int b0,
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
                                                            int row_off, float factor, float na0,
                                                            float na1, float na2, float nb0, float nb1,
                                                            float nb2, int is_template) {
-    __shared__ uint32_t src[PRE_TILE_LDS];
+    __shared__ uint32_t src[LDSPX];
     constexpr int PX = 8;
     const int b = b0 + blockIdx.y;
     const FrameDesc f = frames[b];
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     const int sy_lo = (int)floorf(((float)(ty * PRE_TILE_H) + 0.5f) * scale + y0m);
     const int sy_hi = (int)floorf(((float)(ty * PRE_TILE_H + PRE_TILE_H - 1) + 0.5f) * scale + y0m) + 1;
     const long sw = (long)sx_hi - sx_lo + 1, sh = (long)sy_hi - sy_lo + 1;
-    const bool staged = sw > 0 && sh > 0 && sw * sh <= PRE_TILE_LDS;      // block-uniform
+    const bool staged = sw > 0 && sh > 0 && sw * sh <= LDSPX;      // block-uniform
     if (staged) {
         const int n = (int)(sw * sh), w_ = (int)sw;
         // NV12 planes whose rows start on 8-byte boundaries (the library's packed windows: pack_window; whole
@@ -497,8 +505,18 @@ __global__ __launch_bounds__(256) void preproc_tile_kernel(const FrameDesc* __re
     }
 }
 
+// The smallest buffer tier (0, 1, 2; 3 = none: per-pixel path) whose tile buffer holds the source rectangle of a 64 x
+// 32 output tile of a w x h box, with a few per cent of headroom for a box that grows between the host's knowledge of
+// it and the launch. Only a choice of speed.
+int preproc_tier_for_box(const ModelDims& d, float w, float h, bool is_template) {
+    const float size = (float)(is_template ? d.T : d.S), factor = is_template ? 2.0f : 4.0f;
+    const float scale = 1.06f * factor * sqrtf(fmaxf(w * h, 1.0f)) / size;
+    const float px = (PRE_TILE_W * scale + 3.0f) * (PRE_TILE_H * scale + 3.0f);
+    return px <= PRE_TILE_LDS ? 0 : (px <= 2 * PRE_TILE_LDS ? 1 : (px <= 4 * PRE_TILE_LDS ? 2 : 3));
+}
+
 hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
-                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st) {
+                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st, int tier) {
     const int size = is_template ? d.T : d.S;
     const int row_off = is_template ? 0 : d.nt;
     const float factor = is_template ? 2.0f : 4.0f;
@@ -507,7 +525,9 @@ hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* 
     // store alignment: a run starts at element c*p*p + py*p + px0 of a row of kpad elements
     if (d.patch % 8 == 0 && d.kpad % 8 == 0 && size % PRE_TILE_W == 0 && size % PRE_TILE_H == 0) {
         dim3 grid((size / PRE_TILE_W) * (size / PRE_TILE_H), nb);   // 64 x 32 output tiles, source staged in LDS
-        hipLaunchKernelGGL(preproc_tile_kernel, grid, dim3(256), 0, st, PRE_ARGS);
+        if (tier <= 0) hipLaunchKernelGGL(preproc_tile_kernel<PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
+        else if (tier == 1) hipLaunchKernelGGL(preproc_tile_kernel<2 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
+        else hipLaunchKernelGGL(preproc_tile_kernel<4 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
     } else if (d.patch % 8 == 0 && d.kpad % 8 == 0) {          // 16-B stores
         dim3 grid((size * size / 8 + 255) / 256, nb);
         hipLaunchKernelGGL(preproc_wide_kernel<8>, grid, dim3(256), 0, st, PRE_ARGS);

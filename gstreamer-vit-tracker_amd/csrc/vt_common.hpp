@@ -158,8 +158,10 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
                                  int H, int npad, int mode, hipStream_t st);
 
 // crop + bilinear + normalise -> patch rows; one launch covers streams [b0, b0+nb)
+// tier: the tile kernel's LDS buffer (0: 16 KiB, 1: 32 KiB, 2 or more: 64 KiB), a choice of speed only
 hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* patches,
-                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st);
+                          const ModelDims& d, int b0, int nb, bool is_template, hipStream_t st, int tier = 0);
+int preproc_tier_for_box(const ModelDims& d, float w, float h, bool is_template);
 
 hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st);
 

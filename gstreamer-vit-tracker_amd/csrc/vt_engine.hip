@@ -159,8 +159,12 @@ struct Engine {
     vt_result* h_results = nullptr;
     StreamState* h_state = nullptr;
     // graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    // one captured pass per crop-buffer tier (k_preproc.hip: 16 / 32 / 64 KiB of LDS per tile), captured when first needed
+    static constexpr int TIERS = 3;
+    hipGraph_t graph[TIERS] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t graph_exec[TIERS] = {nullptr, nullptr, nullptr};
+    int crop_tier = 0;                            // tier of the pass being enqueued (from the boxes the host knows)
+    int crop_tier_forced = -1;                    // >= 0: tests / A-B runs (vt_group_set_tuning "crop_tier")
     // host-pointer staging (single-stream API)
     uint8_t* d_stage = nullptr;
     uint8_t* h_pack = nullptr;      // pinned: the window of a host frame, packed
@@ -199,7 +203,9 @@ struct Engine {
     size_t activation_bytes() const;
     int alloc_buffers();
     int run_pass(Profiler* prof);
-    int capture_graph();
+    int capture_graph(int tier);
+    int pick_crop_tier() const;
+    void drop_graphs();
     // host_res / host_st: pinned buffers the pass's results and states are stored to (null: the
     // engine's own h_results / h_states_all)
     int enqueue(const vt_frame* frames, int n, vt_result* host_res = nullptr, StreamState* host_st = nullptr);
@@ -217,8 +223,7 @@ void Engine::destroy() {
     if (!stream && !d_blob) return;
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    drop_graphs();
     void* devp[] = {d_blob, d_patches, d_qk, d_vt, d_attn, d_mlp, d_feat, d_ta, d_tb, d_zeros,
                     d_xh, d_xl, d_cstat, d_rstat, d_panel_cnt, d_band_cnt, d_band_best, d_foldw, d_foldv, d_headout, d_taps, d_states, d_frames,
                     d_results, d_stage};
@@ -244,8 +249,25 @@ void Engine::destroy() {
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
     d_blob = nullptr;
-    graph = nullptr;
-    graph_exec = nullptr;
+}
+
+void Engine::drop_graphs() {
+    for (int t = 0; t < TIERS; ++t) {
+        if (graph_exec[t]) (void)hipGraphExecDestroy(graph_exec[t]);
+        if (graph[t]) (void)hipGraphDestroy(graph[t]);
+        graph_exec[t] = nullptr; graph[t] = nullptr;
+    }
+}
+
+// The crop kernel's buffer tier for the pass about to be enqueued: the largest any stream's last known box needs (the
+// boxes of a pipelined pass are one pass old: targets change by a few per cent per frame, the tier has headroom, and a
+// tile that does not fit its buffer after all takes the per-pixel path - slower, never wrong).
+int Engine::pick_crop_tier() const {
+    if (crop_tier_forced >= 0) return std::min(crop_tier_forced, TIERS - 1);
+    int t = 0;
+    for (int b = 0; b < B && t < TIERS - 1; ++b)
+        t = std::max(t, std::min(preproc_tier_for_box(d, known[b].box[2], known[b].box[3], false), TIERS - 1));
+    return t;
 }
 
 int Engine::index_blob(const uint8_t* hc, size_t bytes) {
@@ -553,7 +575,7 @@ int Engine::run_pass(Profiler* prof) {
 
     // K1: crop + resize + normalise the search window of every stream -> patch rows
     L("preproc_search", 0, (double)B * (d.S * d.S * 3 * 2 + 1.5 * d.S * d.S),
-      [&] { return launch_preproc(d_frames, d_states, d_patches, d, 0, B, false, stream); });
+      [&] { return launch_preproc(d_frames, d_states, d_patches, d, 0, B, false, stream, crop_tier); });
     // K2: patch embedding (+bias +pos) -> residual stream (bf16 pair + chunk statistics)
     {
         GemmArgs a{};
@@ -662,7 +684,8 @@ int Engine::run_pass(Profiler* prof) {
     return VT_OK;     // results and states reach the host through the decode kernel's own stores (PassOut)
 }
 
-int Engine::capture_graph() {
+int Engine::capture_graph(int tier) {
+    crop_tier = tier;
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     int rc = run_pass(nullptr);
     hipGraph_t g = nullptr;
@@ -672,8 +695,8 @@ int Engine::capture_graph() {
         return rc;
     }
     if (e != hipSuccess) return set_err(VT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    graph = g;
-    HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    graph[tier] = g;
+    HIPCHK(hipGraphInstantiate(&graph_exec[tier], graph[tier], nullptr, nullptr, 0));
     return VT_OK;
 }
 
@@ -745,7 +768,8 @@ int Engine::init_stream(int b, const vt_frame* f, vt_bbox box) {
     FrameDesc* slot = h_frames;  // stream is idle: ring slot 0 is free
     to_desc(*f, slot);
     HIPCHK(hipMemcpyAsync(d_frames + b, slot, sizeof(FrameDesc), hipMemcpyHostToDevice, stream));
-    HIPCHK(launch_preproc(d_frames, d_states, d_patches, d, b, 1, true, stream));
+    HIPCHK(launch_preproc(d_frames, d_states, d_patches, d, b, 1, true, stream,
+                          preproc_tier_for_box(d, (float)box.width, (float)box.height, true)));
     HIPCHK(hipStreamSynchronize(stream));
     h_states_all[b] = *h_state;
     known[b] = *h_state;
@@ -768,12 +792,14 @@ int Engine::enqueue(const vt_frame* frames, int n, vt_result* host_res, StreamSt
     *(PassOut*)(hf + B) = PassOut{host_res ? host_res : h_results, host_st ? host_st : h_states_all};
     HIPCHK(hipMemcpyAsync(d_frames, hf, frames_block_bytes(), hipMemcpyHostToDevice, stream));
     HIPCHK(hipEventRecord(ring_ev[slot], stream));
+    const int tier = pick_crop_tier();
     if (use_graph && !taps) {
-        if (!graph_exec)
-            if (int rc = capture_graph()) return rc;
-        HIPCHK(hipGraphLaunch(graph_exec, stream));
+        if (!graph_exec[tier])
+            if (int rc = capture_graph(tier)) return rc;
+        HIPCHK(hipGraphLaunch(graph_exec[tier], stream));
         return VT_OK;
     }
+    crop_tier = tier;
     return run_pass(nullptr);
 }
 
@@ -1189,10 +1215,10 @@ int vt_group_set_tuning(vt_group* g, const char* key, int value) try {
     HIPCHK(hipStreamSynchronize(e->stream));
     const std::string k = key;
     if (k == "head_band") e->head_band_kernel = value != 0;
+    else if (k == "crop_tier") e->crop_tier_forced = value;      // < 0: chosen per pass from the known boxes (default)
     else return set_err(VT_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
-    // the captured pass holds the old choice: drop it, the next pass captures again
-    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    // the captured passes hold the old choice: drop them, the next pass captures again
+    e->drop_graphs();
     return VT_OK;
 } VT_NOTHROW_INT
 
@@ -1234,6 +1260,7 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
     *(PassOut*)(hf + e->B) = PassOut{e->h_results, e->h_states_all};
     HIPCHK(hipMemcpyAsync(e->d_frames, hf, e->frames_block_bytes(), hipMemcpyHostToDevice, e->stream));
     Profiler prof;
+    e->crop_tier = e->pick_crop_tier();
     for (int it = 0; it < iters; ++it)
         if (int rc = e->run_pass(&prof)) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -359,8 +359,9 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
 int vt_group_enable_taps(vt_group* g, int enable);
 /* Diagnostics (A/B measurements and parity tests of alternative kernels; results are the same quantity either
  * way): key "head_band": 1 (default) = the head's convolutions on the band kernel with the logits and the decode
- * fused behind the last layer, 0 = implicit GEMMs + head_out + decode launches. Not while a pipelined pass is
- * outstanding. */
+ * fused behind the last layer, 0 = implicit GEMMs + head_out + decode launches; key "crop_tier": >= 0 forces the crop
+ * kernel's LDS buffer tier (0: 16 KiB, 1: 32 KiB, 2: 64 KiB), < 0 (default) = chosen per pass from the boxes the host
+ * knows. Not while a pipelined pass is outstanding. */
 int vt_group_set_tuning(vt_group* g, const char* key, int value);
 /* A single tracker viewed as a group of one (taps, profiling, stream handle). The view belongs to
  * the tracker: valid until vt_destroy(t), the same pointer on every call, never to be destroyed

@@ -60,13 +60,37 @@ def _patches_case(gpu, oracle, weights, frame_np, oframe, box):
 
 
 @pytest.mark.parametrize("box", [(288, 208, 64, 64), (300, 200, 41, 77), (5, 3, 50, 40),
-                                 (600, 440, 30, 30), (100, 100, 333, 201)])
+                                 (600, 440, 30, 30), (100, 100, 333, 201), (200, 150, 80, 80), (250, 180, 100, 70)])
 def test_patch_matrix_bit_exact_nv12(gpu, oracle, weights_tiny, box):
+    """boxes for every path of the crop kernel at search size 128: 30 px -> the 16-KiB tile buffer, 41x77 / 50x40 / 64 px
+    -> the 32-KiB tier, 80 px / 100x70 -> the 64-KiB tier, 333x201 -> per-pixel fetches (the engine picks the tier from
+    the box it knows: round 5)"""
     sc = gpu.synth.MovingSquare(640, 480, 64, seed=1)
     buf = sc.frame_nv12(0)
     got, want, _, _ = _patches_case(gpu, oracle, weights_tiny, gpu.NV12Frame(buf, 640, 480),
                                     oracle.Frame.nv12(buf, 640, 480), box)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("box", [(288, 208, 64, 64), (200, 150, 80, 80), (600, 440, 30, 30), (100, 100, 333, 201)])
+def test_crop_buffer_tier_changes_no_value(gpu, weights_tiny, box):
+    """the crop kernel's LDS buffer tier is a choice of speed: forced to each tier (vt_group_set_tuning "crop_tier") the
+    patch matrix and the result are identical to the automatic choice - also when the forced buffer is too small for
+    the box (tiles then take the per-pixel path) - graph replay and eager"""
+    w, h = 640, 480
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=1)
+    f = gpu.NV12Frame(sc.frame_nv12(0), w, h)
+    out = []
+    for tier in (-1, 0, 1, 2):
+        for use_graph in (True, False):
+            g = gpu.Group(weights_tiny, n_streams=2, use_graph=use_graph)
+            g.set_tuning("crop_tier", tier)
+            for i in range(2):
+                g.init_host(i, f, gpu.BBox.new(*box))
+            r = [g.update_host([f, f]) for _ in range(2)][-1]
+            out.append((g.read_tensor("patches", 1).tobytes(), [(x.bbox, x.score) for x in r]))
+            del g
+    assert all(o == out[0] for o in out)
 
 
 def test_patch_matrix_bit_exact_yuy2(gpu, oracle, weights_tiny):
