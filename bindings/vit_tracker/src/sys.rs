@@ -1,11 +1,11 @@
-//! Raw declarations of include/vittrack_hip.h (VT_ABI_VERSION 3), one for one and in header order.
+//! Raw declarations of include/vittrack_hip.h (VT_ABI_VERSION 4), one for one and in header order.
 //! tests/test_rust_binding.py parses this file and the header and fails on any drift: a missing or
 //! extra function, a different argument count / order / type, a struct whose fields or size differ.
 #![allow(non_camel_case_types, dead_code)]
 
 use std::ffi::{c_char, c_int, c_void};
 
-pub const VT_ABI_VERSION: c_int = 3;
+pub const VT_ABI_VERSION: c_int = 4;
 pub const VT_MAX_STREAMS: c_int = 1024;
 pub const VT_RCCL_ID_BYTES: usize = 128;
 

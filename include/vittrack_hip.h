@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 3   /* 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
+#define VT_ABI_VERSION 4   /* 4: vt_config.host_zero_copy (a former reserved slot: zero = the old default for single trackers), vt_group_set_tuning, vt_op_headconv_bf16 - additions only, a host built against 3 keeps working; 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
 
 typedef enum vt_status {
     VT_OK = 0,

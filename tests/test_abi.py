@@ -21,7 +21,7 @@ def test_hip_library_exports_every_declared_symbol(vt):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(vt.EXPORTS) == names
-    assert L.vt_abi_version() == 3
+    assert L.vt_abi_version() == 4
 
 
 def test_host_library_exports_every_declared_symbol(vt):
