@@ -212,8 +212,164 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, char* smem, int
 #endif
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
-__global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p) {
+// ---- loader-wave variant of the main loop (round 5; configs 7-10, small batches) ------------------------------------
+// 512 threads: waves 0..3 compute exactly as above (same LDS image, same fragment reads, same MFMA order: bit-identical
+// accumulators), waves 4..7 issue every LDS-DMA piece. At one stream a K-step of the 4-wave kernel is 4 (depth 64) or 8
+// (depth 128) LDS-DMA instructions per wave at ~100 cycles of issue back-pressure each, a barrier and 4-8 MFMAs - the
+// issue stalls, in the computing waves' own instruction streams, were most of it (profiles/r04_deep_ring_small_batch.txt:
+// 0.45-0.55 us per K-step whatever the prefetch distance). Here they run beside the MFMA streams, and the ring can be
+// deep (the loaders run ahead; a stage is refilled one barrier after its last read).
+//   loader, per K-tile:  counted vmcnt (tile kt landed; up to NS - 2 younger tiles stay in flight) | barrier | issue kt + NS - 1
+//   computing wave:      barrier | fragment reads + MFMAs of tile kt
+// One raw s_barrier per K-tile for all eight waves.
+// The loader waves branch off at the top of the kernel, BEFORE the computing waves' hand-waited inline-asm loads (on a
+// path where those loads' values are dead hipcc would be free to reuse their destination registers while the loads are
+// still in flight), run gemm_lw_loader and leave through the epilogue's barriers.
+template <int BM, int BN, int NS, int BK, bool CONV>
+__device__ __forceinline__ void gemm_lw_loader(const GemmArgs& p, char* smem, int m0, int n0) {
+    static_assert(BK == 64 || BK == 128, "K-tile depth");
+    static_assert(NS >= 3, "a ring of at least three stages");
+    constexpr int ROWB = BK * 2, CPR = BK / 8, RPP = 1024 / ROWB;
+    constexpr int PA = BM / (RPP * 4), PB = BN / (RPP * 4);      // 1-KiB LDS-DMA pieces per LOADER wave and stage
+    static_assert(PA >= 1 && PB >= 1, "tile too small for four loader waves");
+    constexpr int STAGE = (BM + BN) * ROWB, IPS = PA + PB;
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : row & 15; };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.K / BK;
+    {
+        // ---- loader wave lw: pieces lw * PA + j of the A rows, lw * PB + j of the W rows --------------------------
+        const int lw = wave - 4;
+        const bf16_t* asrc[PA];
+        const bf16_t* bsrc[PB];
+        int cv_cell[PA], cv_y[PA], cv_x[PA], cv_c[PA];
+        const bool conv = CONV && p.conv_grid > 0;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int row = (lw * PA + j) * RPP + (lane / CPR);
+            const int c = (lane % CPR) ^ swz(row);
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            asrc[j] = p.A + (size_t)gm * p.lda + c * 8;
+            if constexpr (CONV) {
+                const int g = p.conv_grid > 0 ? p.conv_grid : 1, cell = gm % (g * g);
+                cv_cell[j] = gm; cv_y[j] = cell / g; cv_x[j] = cell % g; cv_c[j] = c * 8;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int row = (lw * PB + j) * RPP + (lane / CPR);
+            const int c = (lane % CPR) ^ swz(row);
+            bsrc[j] = p.W + (size_t)(n0 + row) * p.ldw + c * 8;
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sA = smem + buf * STAGE;
+#pragma unroll
+            for (int q = 0; q < PA; ++q) {
+                if (conv) {       // K-tile kt = channels [cc, cc + BK) of tap (ky, kx) of the 3x3 window
+                    const int k0 = kt * BK, tap = k0 / p.conv_C, cc = k0 - tap * p.conv_C;
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int y = cv_y[q] + ky - 1, x = cv_x[q] + kx - 1;
+                    const bool in = y >= 0 && y < p.conv_grid && x >= 0 && x < p.conv_grid;
+                    const bf16_t* src = in ? p.A + (size_t)(cv_cell[q] + (ky - 1) * p.conv_grid + (kx - 1)) * p.lda + cc + cv_c[q]
+                                           : p.zeros + cv_c[q];
+                    glds16(src, sA + (lw * PA + q) * 1024);
+                } else {
+                    glds16(asrc[q] + kt * BK, sA + (lw * PA + q) * 1024);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PB; ++q) glds16(bsrc[q] + kt * BK, sA + BM * ROWB + (lw * PB + q) * 1024);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NS - 1; ++s_)
+            if (s_ < nk) stage(s_, s_);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(NS - 2, nk - 1 - kt);        // younger tiles that may stay in flight
+            switch (ahead) {                                    // s_waitcnt takes an immediate
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<IPS>(); break;
+                case 2: wait_vmcnt<2 * IPS>(); break;
+                case 3: wait_vmcnt<(NS >= 5 ? 3 : 0) * IPS>(); break;
+                default: wait_vmcnt<(NS >= 6 ? 4 : 0) * IPS>(); break;
+            }
+            __builtin_amdgcn_s_barrier();       // tile kt has landed; the computing waves are done with tile kt - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS - 1 < nk) stage(kt + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+        }
+    }
+}
+
+// ---- computing waves: as gemm_mainloop, without the loads ------------------------------------------------------------
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, bool ROW_ON_LANE>
+__device__ __forceinline__ void gemm_lw_compute(const GemmArgs& p, char* smem,
+                                                f32x16_t (&acc)[BM / WVM / 32][BN / WVN / 32]) {
+    static_assert(WVM * WVN == 4, "four computing waves beside four loader waves");
+    constexpr int ROWB = BK * 2;
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
+    constexpr int STAGE = (BM + BN) * ROWB, KS = BK / 16;
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : row & 15; };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.K / BK;
+    const int wr = wave / WVN, wc = wave % WVN;
+    const int l31 = lane & 31, half = lane >> 5;
+    int aoff[TM], boff[TN], aswz[TM], bswz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wr * WM + i * 32 + l31;
+        aoff[i] = row * ROWB;
+        aswz[i] = swz(row);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 32 + l31;
+        boff[j] = BM * ROWB + row * ROWB;
+        bswz[j] = swz(row);
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sbase = smem + cur * STAGE;
+        bf16x8_t af[2][TM], bfr[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[0][i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((half ^ aswz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((half ^ bswz[j]) << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cb = ks & 1, nb = cb ^ 1;
+            if (ks < KS - 1) {
+                const int c = 2 * (ks + 1) + half;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[nb][i] = *reinterpret_cast<const bf16x8_t*>(sbase + aoff[i] + ((c ^ aswz[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[nb][j] = *reinterpret_cast<const bf16x8_t*>(sbase + boff[j] + ((c ^ bswz[j]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (ROW_ON_LANE)  // D[n][m]: lane = m (row of C), registers = n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][j], af[cb][i], acc[i][j], 0, 0, 0);
+                    else              // D[m][n]: lane = n (column of C), registers = m
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cb][i], bfr[cb][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+    }
+}
+
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI, bool LW = false>
+__global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
     const int tiles_n = p.N / BN;
@@ -229,6 +385,18 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
     }
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
+    if constexpr (LW) {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4) {     // loader waves (see gemm_lw_loader)
+            gemm_lw_loader<BM, BN, NS, BK, EPI == EPI_RELU_BF16>(p, smem, m0, n0);
+            constexpr bool XEPI = EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32;
+            constexpr bool FITS_ = BM * (BN * 2 + 16) <= ring_bytes(NS, BM, BN, BK) && BN * (BM * 2 + 16) <= ring_bytes(NS, BM, BN, BK);
+            if constexpr (XEPI || FITS_) { __syncthreads(); __syncthreads(); }    // the epilogue's two workgroup barriers
+            // s_endpgm here, not a `return` merged with the computing waves' exit: a merged exit makes hipcc lay the
+            // loader code out BEHIND the computing path, guarded by a flag, and the build-time check of the hand-waited
+            // loads (tests/test_isa_asm_loads.py, path-insensitive) then sees an infeasible path into it
+            __builtin_amdgcn_endpgm();
+        }
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WVN, wc = wave % WVN, l31 = lane & 31, half = lane >> 5;
 
@@ -277,7 +445,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
                 }
             }
         }
-        gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true>(p, smem, m0, n0, acc);
+        if constexpr (LW) gemm_lw_compute<BM, BN, WVM, WVN, NS, BK, true>(p, smem, acc);
+        else gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true>(p, smem, m0, n0, acc);
         __syncthreads();                       // every wave has finished reading the ring
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -384,7 +553,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         }
         if (!v_tile) {
             // row-major [m][n]: MFMA with the row on the lane, 4 consecutive n per register quad
-            gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
+            if constexpr (LW) gemm_lw_compute<BM, BN, WVM, WVN, NS, BK, true>(p, smem, acc);
+            else gemm_mainloop<BM, BN, WVM, WVN, NS, BK, true, EPI == EPI_RELU_BF16>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BN * 2 + 16;
             if constexpr (FITS) __syncthreads();
             // folded LayerNorm: y = a_r * acc + (b_r * colsum[n] + bias[n]); without one a_r = 1, b_r = 0
@@ -451,7 +621,8 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t] with t contiguous (npad per row). MFMA with the
             // column (d) on the lane, 4 consecutive tokens per register quad.
-            gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
+            if constexpr (LW) gemm_lw_compute<BM, BN, WVM, WVN, NS, BK, false>(p, smem, acc);
+            else gemm_mainloop<BM, BN, WVM, WVN, NS, BK, false>(p, smem, m0, n0, acc);
             constexpr int STRIDE = BM * 2 + 16;
             const int heads = p.D >> 6;
             // folded LayerNorm: the row terms of the 16 rows per 32-row block this lane's registers hold,
@@ -560,29 +731,36 @@ __global__ __launch_bounds__(WVM * WVN * 64, 2) void gemm_bf16_kernel(GemmArgs p
 // (256-wide tiles with the same loop, 8-wave blocks, deeper rings, K-tile depth 32, register
 // staging) that never beat 128x128 ring 2 and were removed after the sweep kept in
 // profiles/gemm_sweep_r01.txt.
+//   7: 64x64   ring 3 k128 + 4 LOADER waves (round 5: 512 threads, gemm_lw_loader / gemm_lw_compute): the one-stream
+//              residual GEMMs (proj, fc2: 144 tiles, one long tile per CU)
+//   8: 128x64  ring 3 k128 + 4 loader waves: fc2 of two / three streams
+// (measured and dropped, profiles/r05_loader_wave_small_batch.txt: 64x64 ring 4 / 6 k64 and ring 4 k128, 128x64 ring 4 k64,
+//  128x128 ring 4 k64 with loader waves)
 #define GEMM_FOR_EACH_CFG(X, EPI) \
-    X(0, 64, 64, 2, 2, 4, 64, EPI)    \
-    X(1, 128, 128, 2, 2, 3, 64, EPI)  \
-    X(2, 64, 64, 2, 2, 2, 64, EPI)    \
-    X(3, 128, 128, 2, 2, 2, 64, EPI)  \
-    X(4, 64, 64, 2, 2, 3, 128, EPI)   \
-    X(5, 64, 64, 2, 2, 2, 128, EPI)   \
-    X(6, 128, 128, 2, 2, 2, 128, EPI)
-#define GEMM_NUM_CFG 20   // valid: 0..6 (this file) and 17, 18, 19 (k_gemm256.hip)
+    X(0, 64, 64, 2, 2, 4, 64, EPI, false)    \
+    X(1, 128, 128, 2, 2, 3, 64, EPI, false)  \
+    X(2, 64, 64, 2, 2, 2, 64, EPI, false)    \
+    X(3, 128, 128, 2, 2, 2, 64, EPI, false)  \
+    X(4, 64, 64, 2, 2, 3, 128, EPI, false)   \
+    X(5, 64, 64, 2, 2, 2, 128, EPI, false)   \
+    X(6, 128, 128, 2, 2, 2, 128, EPI, false) \
+    X(7, 64, 64, 2, 2, 3, 128, EPI, true)    \
+    X(8, 128, 64, 2, 2, 3, 128, EPI, true)
+#define GEMM_NUM_CFG 20   // valid: 0..8 (this file) and 17, 18, 19 (k_gemm256.hip)
 
-template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI, bool LW>
 static hipError_t prepare_cfg() {
     constexpr int smem = ring_bytes(NS, BM, BN, BK);
     return hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI>),
+        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI, LW>),
         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 template <int EPI>
 static hipError_t prepare_epi() {
     hipError_t e = hipSuccess;
-#define X(id, BM, BN, WVM, WVN, NS, BK, E) \
-    if (e == hipSuccess) e = prepare_cfg<BM, BN, WVM, WVN, NS, BK, E>();
+#define X(id, BM, BN, WVM, WVN, NS, BK, E, LW) \
+    if (e == hipSuccess) e = prepare_cfg<BM, BN, WVM, WVN, NS, BK, E, LW>();
     GEMM_FOR_EACH_CFG(X, EPI)
 #undef X
     return e;
@@ -600,15 +778,15 @@ hipError_t gemm_prepare() {
     return gemm256_prepare();
 }
 
-template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI>
+template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI, bool LW>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = ring_bytes(NS, BM, BN, BK);
     if (a.N % BN != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     if (a.conv_grid > 0 && a.conv_C % BK != 0) return hipErrorInvalidValue;   // a K-tile lies inside one tap
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI>), dim3(tiles),
-                       dim3(WVM * WVN * 64), smem, st, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI, LW>), dim3(tiles),
+                       dim3(WVM * WVN * 64 * (LW ? 2 : 1)), smem, st, a);
     return hipGetLastError();
 }
 
@@ -652,12 +830,17 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
             if (tiles128 <= 64 && k128 && (!conv || (N % 128) == 0)) return 4;
             return 2;
         case EPI_RESID:
+            // round 5 (profiles/r05_loader_wave_small_batch.txt): with four loader waves beside the four computing
+            // waves (configs 7, 8) the one-stream residual GEMMs - 144 tiles, one per CU, each a long K loop - run at
+            // the CU's LDS fill rate: fc2 14.5 -> 12.7 us, proj 6.1 -> 5.5 (config 7); fc2 of two / three streams
+            // 21.3 -> 19.8 / 22.4 -> 20.9 (config 8). QKV and fc1 (2-3 short tiles per CU) do not gain and keep theirs.
             if (K >= 2048) {                       // fc2: long dependent K loop
-                if (M <= 1024 && k128) return 4;
+                if (M <= 1024 && k128) return 7;
+                if (M <= 2304 && k128) return 8;
                 if (M <= 2304) return 0;
                 if (n128) return tiles128 < 256 ? 1 : 3;
             }
-            if (k128 && M <= 1024) return 4;       // proj, one stream
+            if (k128 && M <= 1024) return 7;       // proj, one stream
             if (k128 && M <= 2304) return 5;
             return (n128 && tiles128 >= 256) ? 3 : 2;     // proj: 8-14 streams (beyond, the 256x256 kernel)
         default: return 2;
@@ -665,18 +848,19 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
 }
 
 const char* gemm_config_name(int cfg) {
-    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "64x64x3k128", "64x64x2k128", "128x128x2k128"};
+    static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "64x64x3k128", "64x64x2k128", "128x128x2k128",
+                              "64x64x3k128lw", "128x64x3k128lw"};
     if (cfg == GEMM_CFG_256P8) return "256x256p8";
     if (cfg == GEMM_CFG_256P4) return "256x256p4";
     if (cfg == GEMM_CFG_256PP) return "256x256pp";
-    return (cfg >= 0 && cfg < 7) ? n[cfg] : "?";
+    return (cfg >= 0 && cfg <= GEMM_CFG_SMALL_MAX) ? n[cfg] : "?";
 }
 
 template <int EPI>
 static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
     switch (cfg) {
-#define X(id, BM, BN, WVM, WVN, NS, BK, E) \
-    case id: return launch_cfg<BM, BN, WVM, WVN, NS, BK, E>(a, st);
+#define X(id, BM, BN, WVM, WVN, NS, BK, E, LW) \
+    case id: return launch_cfg<BM, BN, WVM, WVN, NS, BK, E, LW>(a, st);
         GEMM_FOR_EACH_CFG(X, EPI)
 #undef X
         default: return hipErrorInvalidValue;
@@ -685,7 +869,7 @@ static hipError_t launch_epi(const GemmArgs& a, int cfg, hipStream_t st) {
 
 hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t st) {
     if (a.M <= 0 || a.N % 64 != 0 || a.K % GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
-    if (a.conv_grid > 0 && (epilogue != EPI_RELU_BF16 || cfg > 6 || a.conv_C % GEMM_BK != 0 || a.K != 9 * a.conv_C ||
+    if (a.conv_grid > 0 && (epilogue != EPI_RELU_BF16 || cfg > GEMM_CFG_SMALL_MAX || a.conv_C % GEMM_BK != 0 || a.K != 9 * a.conv_C ||
                             a.lda != a.conv_C || !a.zeros || a.M % (a.conv_grid * a.conv_grid) != 0))
         return hipErrorInvalidValue;
     if (epilogue == EPI_QKV && (a.D % 64 != 0 || (a.tokens & 3) != 0 || (a.npad & 3) != 0))
@@ -694,7 +878,7 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
     if (x_epi && (!a.Xh || !a.Xl || (a.ldx & 7) || (epilogue == EPI_F32_POS && (!a.pos || a.pos_rows < 1))))
         return hipErrorInvalidValue;
     if (!x_epi && (!a.bias || ((a.rowstat || a.cstat_in) && !a.colsum))) return hipErrorInvalidValue;
-    if (a.cstat_in && (cfg > 6 || a.rowstat || (a.K % (4 * VT_STAT_CHUNK)) != 0 || a.K > 1024)) return hipErrorInvalidValue;
+    if (a.cstat_in && (cfg > GEMM_CFG_SMALL_MAX || a.rowstat || (a.K % (4 * VT_STAT_CHUNK)) != 0 || a.K > 1024)) return hipErrorInvalidValue;
     if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
     if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
     if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);

@@ -113,6 +113,7 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv = false);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
 // k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
+#define GEMM_CFG_SMALL_MAX 8   // 0..8: the 4-wave kernel of k_gemm.hip (7, 8 with four loader waves beside it)
 #define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
 #define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
 #define GEMM_CFG_256PP 19      // v2, persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)

@@ -553,7 +553,7 @@ int Engine::run_pass(Profiler* prof) {
         gemm(epi, a);
         if (!stats) return;
         consumer->ln_eps = d.ln_eps;
-        if (!fused && gemm_effective_config(*consumer, consumer_epi) <= 6 && consumer->K <= 1024 && consumer->K % 128 == 0) {
+        if (!fused && gemm_effective_config(*consumer, consumer_epi) <= GEMM_CFG_SMALL_MAX && consumer->K <= 1024 && consumer->K % 128 == 0) {
             consumer->cstat_in = d_cstat;       // combined in the consumer's epilogue
             return;
         }
@@ -2215,7 +2215,7 @@ int vt_op_layernorm(int device_id, const float* x, const float* gamma, const flo
 // widened to f32. cfg 0..3 (4-wave kernel), < 0: the launcher's choice.
 int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
                             int B, int grid, int C, int N, int cfg) try {
-    if (!t || !w || !bias || !out || B < 1 || grid < 1 || C % 64 || N % 64 || cfg > 6)
+    if (!t || !w || !bias || !out || B < 1 || grid < 1 || C % 64 || N % 64 || cfg > GEMM_CFG_SMALL_MAX)
         return set_err(VT_ERR_INVALID_ARG, "bad argument");
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);

@@ -34,7 +34,7 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, cfg, epi):
     """each tile configuration (64x64 / 128x128 with ring 2..4 and K-tile depth 64, 4-6: depth 128,
@@ -56,7 +56,7 @@ def test_gemm_every_tile_config(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
 def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)
     B, tokens, D = 2, 100, 768
@@ -84,7 +84,7 @@ def test_gemm_exact_integers_asymmetric(gpu):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (720, 768, 3072), (131, 128, 256), (1000, 768, 1024)])
 def test_gemm_4wave_exact_integers(gpu, M, N, K, cfg):
     """the 4-wave kernel's tile configurations (K-tile depth 64 and 128: different LDS row length,
@@ -364,7 +364,8 @@ def test_layernorm(gpu, M, D):
 
 
 @pytest.mark.parametrize("B,grid,C,N,cfg", [(1, 24, 128, 128, 2), (3, 24, 128, 128, 3), (2, 8, 64, 64, 0), (2, 24, 128, 128, 4),
-                                             (30, 24, 128, 128, -1), (1, 28, 128, 128, 1), (5, 5, 64, 128, 2)])
+                                             (30, 24, 128, 128, -1), (1, 28, 128, 128, 1), (5, 5, 64, 128, 2),
+                                             (2, 24, 128, 128, 7), (1, 24, 128, 128, 8)])
 def test_head_conv3x3_as_implicit_gemm(gpu, B, grid, C, N, cfg):
     """the head's 3x3 convolutions gather their im2col rows inside the GEMM's A loads (no im2col
     kernel, no column buffer): exact small integers against a direct NumPy convolution with zero
@@ -491,7 +492,7 @@ def _row_terms(x, eps=1e-6):
     return np.stack([rstd, -mean * rstd], axis=1)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18])
 @pytest.mark.parametrize("epi", [0, 1, 4])
 def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
     """the three epilogues that write the residual stream (0 plain, 1 += old pair, 4 += positional rows):
@@ -533,7 +534,7 @@ def test_x_epilogues_exact_integers(gpu, cfg):
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=4, cfg=cfg), ref + c0)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
 @pytest.mark.parametrize("epi", [2, 3])
 def test_folded_layernorm_in_the_bf16_epilogues(gpu, cfg, epi):
     """y = rowstat[m][0] * acc + (rowstat[m][1] * colsum[n] + bias[n]) ahead of GELU / ReLU: integer
