@@ -208,6 +208,7 @@ extern "C" {
     pub fn vt_op_gemm_bench(device_id: c_int, m: c_int, n: c_int, k: c_int, epilogue: c_int, cfg: c_int, iters: c_int, us_out: *mut f32) -> c_int;
     pub fn vt_op_conv3x3_relu_bf16(device_id: c_int, t: *const u16, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, c: c_int, n: c_int, cfg: c_int) -> c_int;
     pub fn vt_op_headconv_bf16(device_id: c_int, t: *const u16, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, cin: c_int, n: c_int, conv3x3: c_int, r: c_int, ncb: c_int, iters: c_int, us_out: *mut f32) -> c_int;
+    pub fn vt_op_headconv_ln_bf16(device_id: c_int, xh: *const u16, xl: *const u16, gamma: *const f32, beta: *const f32, eps: f32, ntok: c_int, off: c_int, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, d: c_int, n: c_int, fused: c_int, r: c_int, ncb: c_int, iters: c_int, us_out: *mut f32) -> c_int;
     pub fn vt_op_qkv_bf16(device_id: c_int, a: *const u16, w: *const u16, bias: *const f32, qk_out: *mut f32, vt_out: *mut f32, b: c_int, tokens: c_int, d: c_int, cfg: c_int, vt_perm: c_int, rowstat_in: *const f32, colsum: *const f32) -> c_int;
     pub fn vt_op_attention_bf16(device_id: c_int, q: *const u16, k: *const u16, v: *const u16, out: *mut f32, b: c_int, n: c_int, h: c_int, mode: c_int) -> c_int;
     pub fn vt_op_attention_bench(device_id: c_int, b: c_int, n: c_int, h: c_int, mode: c_int, iters: c_int, us_out: *mut f32) -> c_int;

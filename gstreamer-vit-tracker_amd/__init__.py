@@ -90,6 +90,7 @@ EXPORTS = [
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_tuning", "vt_group_set_state_box", "vt_tracker_as_group",
     "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
     "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_conv3x3_relu_bf16", "vt_op_headconv_bf16",
+    "vt_op_headconv_ln_bf16",
     "vt_rccl_unique_id", "vt_broadcast_weights_rccl", "vt_free_device_blob",
 ]
 
@@ -760,6 +761,33 @@ def op_headconv(t_bf16_bits, w_bf16_bits, bias, B, grid, conv3x3=True, R=0, ncb=
                                      _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, Cin, N,
                                      1 if conv3x3 else 0, R, ncb, 0, None))
     return out
+
+
+def op_headconv_ln(xh_bits, xl_bits, gamma, beta, w_bf16_bits, bias, B, grid, ntok, off, fused=True, eps=1e-6, R=0, ncb=0,
+                   device=0):
+    """vt_op_headconv_ln_bf16: relu(LayerNorm(xh + xl)[search rows] . w^T + bias) -> [B*grid*grid][N] float32; fused: one
+    launch (the band kernel normalises its rows itself), else the LayerNorm kernel followed by the band kernel"""
+    xh = np.ascontiguousarray(xh_bits, np.uint16)
+    xl = np.ascontiguousarray(xl_bits, np.uint16)
+    w = np.ascontiguousarray(w_bf16_bits, np.uint16)
+    D, N = xh.shape[1], w.shape[0]
+    assert xh.shape == xl.shape == (B * ntok, D) and w.shape[1] == D
+    out = np.empty((B * grid * grid, N), np.float32)
+    u16 = POINTER(ctypes.c_uint16)
+    _check(lib().vt_op_headconv_ln_bf16(device, xh.ctypes.data_as(u16), xl.ctypes.data_as(u16),
+                                        _f32(np.ascontiguousarray(gamma, np.float32)),
+                                        _f32(np.ascontiguousarray(beta, np.float32)), c_float(eps), ntok, off,
+                                        w.ctypes.data_as(u16), _f32(np.ascontiguousarray(bias, np.float32)), _f32(out),
+                                        B, grid, D, N, 1 if fused else 0, R, ncb, 0, None))
+    return out
+
+
+def op_headconv_ln_bench(B, grid, D, N, ntok, off, fused=True, R=0, ncb=0, iters=50, device=0) -> float:
+    """mean microseconds of the head's first layer with the final LayerNorm (fused: one launch, else two)"""
+    us = c_float()
+    _check(lib().vt_op_headconv_ln_bf16(device, None, None, None, None, c_float(1e-6), ntok, off, None, None, None, B, grid,
+                                        D, N, 1 if fused else 0, R, ncb, iters, byref(us)))
+    return float(us.value)
 
 
 def op_headconv_bench(B, grid, Cin, N, conv3x3=True, R=0, ncb=0, iters=50, device=0) -> float:

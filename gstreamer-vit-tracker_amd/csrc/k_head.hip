@@ -253,7 +253,13 @@ __device__ __forceinline__ float row8_sum(float v) {
 // issue stalls; a loader wave stalls beside a computing wave's MFMA stream instead (the guide's ring-gemm structure).
 // One raw barrier per K-tile for all eight waves: the loaders pass it after their counted vmcnt (tile kt has landed),
 // the computing waves after the MFMAs of tile kt - 1 (its stage may be refilled).
-template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+// LNC > 0 (1x1 layer only): the layer's input is the final LayerNorm of the split residual stream (D = 256 * LNC),
+// computed by the workgroup itself for its band's rows: all eight waves normalise the rows (half a wave per row, the
+// arithmetic of ln_row - the LayerNorm kernel's own) straight into a RESIDENT A image [K-tile][row][128 B] in the ring's
+// swizzle, while the first weight tiles are in flight; the main loop then streams the weights only. The LayerNorm as a
+// launch of its own (53 MB read, 26.5 MB written, and the 1x1 layer reading them back: 17 + 12 us of a 30-stream pass at
+// cfg3) becomes the 53 MB read of this kernel.
+template <int BK, int NCB, int MB, bool HALO, bool TAIL, int LNC = 0>
 __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeArgs dec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 512;
@@ -261,10 +267,12 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
     constexpr int CPR = ROWB / 16;                // 16-B chunks per row (8 or 16)
     constexpr int RPP = 1024 / ROWB;              // rows per 1-KiB LDS-DMA piece (8 or 4)
     constexpr int BN = 64 * NCB;
-    constexpr int NS = HALO ? 3 : 4;              // ring stages
+    constexpr bool RES = HALO || LNC > 0;         // the A operand is resident in LDS: the ring carries weights only
+    constexpr int NS = RES ? 3 : 4;               // ring stages
     constexpr int WPW = BN / RPP / 4;             // W pieces per loader wave and stage
     static_assert(BK == 64 || BK == 128, "K-tile depth");
     static_assert(!TAIL || HALO, "the fused tail follows a 3x3 layer");
+    static_assert(LNC == 0 || (!HALO && BK == 64), "the fused LayerNorm feeds the 1x1 layer");
     // LDS images: rows of ROWB bytes, 16-B chunk c of a row stored at chunk slot slot_of(c, key) (LDS-DMA writes lane-
     // linear, so the permutation is applied to the per-lane SOURCE chunk - chunk_at - and again on the read).
     // 128-B rows (two per bank line): slot = c ^ key with key = row >> 1 - the 4-wave GEMM's swizzle, conflict-free for the
@@ -299,11 +307,12 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
     // LDS: [A image (HALO) | ring of NS stages]; a stage = [A rows (stream mode) | BN weight rows]
     const int hw = grid + 2;
     const int hcells = HALO ? (p.R + 2) * hw : 0;
-    const int himg = HALO ? ((hcells + RPP - 1) / RPP) * RPP * ROWB : 0;
+    const int a_tile = LNC > 0 ? p.R * grid * ROWB : 0;        // LNC: one K-tile of the resident A image (all band rows)
+    const int himg = HALO ? ((hcells + RPP - 1) / RPP) * RPP * ROWB : LNC > 0 ? ((p.K / BK) * a_tile + 1023) & ~1023 : 0;
     constexpr int MBE = (MB + 1) & ~1;            // stream mode: an even number of row blocks (pieces divide over 4 waves)
-    constexpr int a_stage = HALO ? 0 : MBE * 16 * ROWB;
+    constexpr int a_stage = RES ? 0 : MBE * 16 * ROWB;
     constexpr int stage = a_stage + BN * ROWB;
-    constexpr int APW = HALO ? 0 : MBE / 2;        // stream mode: MBE / 2 pieces of 8 rows per loader wave (ROWB 128)
+    constexpr int APW = RES ? 0 : MBE / 2;         // stream mode: MBE / 2 pieces of 8 rows per loader wave (ROWB 128)
     constexpr int IPS = WPW + APW;                 // LDS-DMA pieces per loader wave and stage
     char* ring = smem + himg;
     const int ntile = HALO ? 9 : p.K / BK;
@@ -333,11 +342,48 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
         }
     }
 
+    // LNC: the band's rows, normalised into the A image. Half-wave h of the 16 takes rows h, h + 16, ...; the raw rows
+    // are fetched two iterations ahead (a row is one memory round trip, a band five of them back to back otherwise).
+    auto ln_phase = [&]() {
+        if constexpr (LNC > 0) {
+            const int l32 = lane & 31, hwv = tid >> 5;
+            const int D = p.K;
+            const size_t tok0 = (size_t)b * p.in_stride + p.in_off + y0 * grid;
+            u32x4_t rh[3][LNC], rl[3][LNC];
+            auto fetch = [&](int it, int slot) {
+                int r = it * 16 + hwv;
+                r = r < cells ? r : cells - 1;
+                const u32x4_t* hr = reinterpret_cast<const u32x4_t*>(p.xh + (tok0 + r) * D);
+                const u32x4_t* lr = reinterpret_cast<const u32x4_t*>(p.xl + (tok0 + r) * D);
+#pragma unroll
+                for (int j = 0; j < LNC; ++j) { rh[slot][j] = hr[l32 + 32 * j]; rl[slot][j] = lr[l32 + 32 * j]; }
+            };
+            fetch(0, 0);
+            if (MB > 1) fetch(1, 1);
+            LnCoef<LNC> k;
+            ln_load_coef<LNC>(p.ln_g, p.ln_b, l32, k);
+#pragma unroll
+            for (int it = 0; it < MB; ++it) {
+                if (it + 2 < MB) fetch(it + 2, (it + 2) % 3);
+                const int r = it * 16 + hwv;
+                f32x4_t v[LNC][2];
+#pragma unroll
+                for (int j = 0; j < LNC; ++j) ln_unpack_split(rh[it % 3][j], rl[it % 3][j], v[j]);
+                uint4 o[LNC];
+                ln_row<LNC>(v, k, D, p.ln_eps, o);
+                if (r < cells) {
+#pragma unroll
+                    for (int j = 0; j < LNC; ++j) {
+                        const int c = l32 + 32 * j;                   // 16-B chunk of the row: K-tile c >> 3, chunk c & 7
+                        *reinterpret_cast<uint4*>(smem + (c >> 3) * a_tile + r * ROWB + (slot_of(c & 7, key_of_row(r)) << 4)) = o[j];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows are in LDS before this wave's first barrier
+        }
+    };
+
     f32x4_t acc[MB][NCB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 
     if (loader) {
         // ---- loader waves: A image, then the ring -------------------------------------------------------------
@@ -382,6 +428,7 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 #pragma unroll
         for (int s_ = 0; s_ < NS - 1; ++s_)
             if (s_ < ntile) issue_tile(s_, s_);
+        ln_phase();                                  // (LNC) beside the first weight tiles' flight
         int cur = 0;
 #ifdef VT_STAMPS
         unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
@@ -417,6 +464,11 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 #endif
     } else {
         // ---- computing waves -------------------------------------------------------------------------------------
+        ln_phase();
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         // fragment addresses. W rows of this wave: wave * 16 * NCB + j * 16 + l15
         int woff[NCB], wsw[NCB];
 #pragma unroll
@@ -437,7 +489,7 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
                 h0[i] = y * hw + x;
                 cm[i] = (y0 + y - 1) * grid + x - 1;
             } else {
-                h0[i] = i * 16 + l15;
+                h0[i] = LNC > 0 ? cell : i * 16 + l15;     // resident A image: the band's rows only
                 cm[i] = 0;
             }
         }
@@ -468,8 +520,9 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
                     a0[i] = (uint32_t)(h * ROWB + (slot_of(lq, BK == 64 ? h >> 1 : cm[i] + koff) << 4));
                 }
             } else {
+                const uint32_t abase = LNC > 0 ? (uint32_t)(kt * a_tile) : sbase;
 #pragma unroll
-                for (int i = 0; i < MB; ++i) a0[i] = sbase + (uint32_t)(h0[i] * ROWB + (slot_of(lq, key_of_row(h0[i])) << 4));
+                for (int i = 0; i < MB; ++i) a0[i] = abase + (uint32_t)(h0[i] * ROWB + (slot_of(lq, key_of_row(h0[i])) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NCB; ++j) w0[j] = sbase + (uint32_t)(woff[j] + (slot_of(lq, wsw[j]) << 4));
@@ -674,9 +727,26 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
 // ---- launch plan -----------------------------------------------------------------------------------------
 // Rows per band R and column groups: one round of workgroups over the 256 CUs where the batch allows it, and
 // the least bytes through one CU (the weights of its column group + its A image): see the header.
-static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool tail, int* R_out, int* ncb_out) {
+// LDS bytes of a launch (0: the band does not fit): [A image | max(ring, staged output tile)]
+static size_t headconv_lds(int grid, int C, int N, int K, bool halo, bool tail, bool ln, int R, int ncb) {
+    const int BN = 64 * ncb, mb = (R * grid + 15) / 16, mbe = (mb + 1) & ~1;
+    const int BK = halo ? C : 64, rowb = BK * 2, rpp = 1024 / rowb;
+    const size_t himg = halo ? (size_t)(((R + 2) * (grid + 2) + rpp - 1) / rpp) * rpp * rowb
+                             : ln ? (((size_t)(K / 64) * R * grid * rowb) + 1023) & ~(size_t)1023 : 0;
+    const size_t stage = ((halo || ln) ? 0 : (size_t)mbe * 16 * rowb) + (size_t)BN * rowb;
+    const size_t ring = ((halo || ln) ? 3 : 4) * stage;
+    const size_t otile = (size_t)mb * 16 * (BN * 2 + 16);
+    size_t smem = himg + std::max(ring, std::max(otile, (size_t)8192));
+    // the fused tail's hand-off (write-through stores, ticket, sc1 loads in place of an acquire) is the form the MI355X
+    // guide measured with ONE workgroup per CU: small models would fit several, so the tail asks for more than half a
+    // CU's LDS (as the 256x256 GEMM's row-panel hand-off has by construction)
+    if (tail) smem = std::max(smem, (size_t)84 * 1024);
+    return smem <= 160 * 1024 ? smem : 0;
+}
+
+static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool tail, bool ln, int* R_out, int* ncb_out) {
     double best = 1e30;
-    int bestR = 1, bestncb = N >= 128 ? 2 : 1;
+    int bestR = 0, bestncb = N >= 128 ? 2 : 1;
     for (int ncb = (N % 128 == 0) ? 2 : 1; ncb >= 1; --ncb) {
         const int BN = 64 * ncb;
         if (N % BN) continue;
@@ -684,11 +754,12 @@ static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool 
         for (int R = 1; R <= grid; ++R) {
             const int mb = (R * grid + 15) / 16;
             if (mb > HC_MBMAX) break;
+            if (!headconv_lds(grid, C, N, K, halo, tail, ln, R, ncb)) break;
             const int bands = (grid + R - 1) / R;
             const long wgs = (long)B * bands * (N / BN);
             const long rounds = (wgs + 255) / 256;
             const double wbytes = (double)BN * K * 2;
-            const double abytes = halo ? (double)(R + 2) * (grid + 2) * C * 2 : (double)mb * 16 * K * 2;
+            const double abytes = halo ? (double)(R + 2) * (grid + 2) * C * 2 : (double)mb * 16 * K * (ln ? 4 : 2);
             const double stream_us = (wbytes + abytes) / 70e3;              // ~70 GB/s per CU from L2
             const double mfma_us = (double)mb * ncb * (K / 32) * 16 / 1.9e3;  // 16 cycles per MFMA, one wave per SIMD
             const double t = rounds * (std::max(stream_us, mfma_us) + 0.5) + 0.002 * bands;
@@ -698,39 +769,39 @@ static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool 
     *R_out = bestR; *ncb_out = bestncb;
 }
 
-template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+template <int BK, int NCB, int MB, bool HALO, bool TAIL, int LNC>
 static hipError_t headconv_launch_t(const HeadConvArgs& a, const DecodeArgs& dec, int wgs, size_t smem, hipStream_t st) {
-    hipLaunchKernelGGL((head_conv_kernel<BK, NCB, MB, HALO, TAIL>), dim3(wgs), dim3(512), smem, st, a, dec);
+    hipLaunchKernelGGL((head_conv_kernel<BK, NCB, MB, HALO, TAIL, LNC>), dim3(wgs), dim3(512), smem, st, a, dec);
     return hipGetLastError();
 }
-template <int BK, int NCB, bool HALO, bool TAIL>
+template <int BK, int NCB, bool HALO, bool TAIL, int LNC = 0>
 static hipError_t headconv_launch_mb(int mb, const HeadConvArgs& a, const DecodeArgs& dec, int wgs, size_t smem, hipStream_t st) {
     switch (mb) {
-        case 1: return headconv_launch_t<BK, NCB, 1, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 2: return headconv_launch_t<BK, NCB, 2, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 3: return headconv_launch_t<BK, NCB, 3, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 4: return headconv_launch_t<BK, NCB, 4, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 5: return headconv_launch_t<BK, NCB, 5, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 6: return headconv_launch_t<BK, NCB, 6, HALO, TAIL>(a, dec, wgs, smem, st);
-        case 7: return headconv_launch_t<BK, NCB, 7, HALO, TAIL>(a, dec, wgs, smem, st);
+        case 1: return headconv_launch_t<BK, NCB, 1, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 2: return headconv_launch_t<BK, NCB, 2, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 3: return headconv_launch_t<BK, NCB, 3, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 4: return headconv_launch_t<BK, NCB, 4, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 5: return headconv_launch_t<BK, NCB, 5, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 6: return headconv_launch_t<BK, NCB, 6, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
+        case 7: return headconv_launch_t<BK, NCB, 7, HALO, TAIL, LNC>(a, dec, wgs, smem, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-template <int BK, int NCB, int MB, bool HALO, bool TAIL>
+template <int BK, int NCB, int MB, bool HALO, bool TAIL, int LNC>
 static hipError_t headconv_prep_t() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&head_conv_kernel<BK, NCB, MB, HALO, TAIL>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&head_conv_kernel<BK, NCB, MB, HALO, TAIL, LNC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
-template <int BK, int NCB, bool HALO, bool TAIL>
+template <int BK, int NCB, bool HALO, bool TAIL, int LNC = 0>
 static hipError_t headconv_prep_mb() {
-    hipError_t e = headconv_prep_t<BK, NCB, 1, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 2, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 3, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 4, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 5, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 6, HALO, TAIL>();
-    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 7, HALO, TAIL>();
+    hipError_t e = headconv_prep_t<BK, NCB, 1, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 2, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 3, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 4, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 5, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 6, HALO, TAIL, LNC>();
+    if (e == hipSuccess) e = headconv_prep_t<BK, NCB, 7, HALO, TAIL, LNC>();
     return e;
 }
 
@@ -743,6 +814,10 @@ hipError_t headconv_prepare() {
     if (e == hipSuccess) e = headconv_prep_mb<64, 1, true, true>();
     if (e == hipSuccess) e = headconv_prep_mb<64, 1, false, false>();
     if (e == hipSuccess) e = headconv_prep_mb<64, 2, false, false>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 1, false, false, 3>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 2, false, false, 3>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 1, false, false, 4>();
+    if (e == hipSuccess) e = headconv_prep_mb<64, 2, false, false, 4>();
     return e;
 }
 
@@ -752,34 +827,39 @@ bool headconv_supported(int grid, int C, int N, int K, bool conv3x3) {
     return (N == 64 || N == 128) && K % 64 == 0 && K >= 64;
 }
 
+// the 1x1 layer with the final LayerNorm inside (a.xh / a.xl / a.ln_g / a.ln_b set): D = 768 or 1024, and a band of at
+// least one map row must fit LDS as a resident image
+bool headconv_ln_supported(int grid, int N, int D) {
+    if (!headconv_supported(grid, N, N, D, false) || (D != 768 && D != 1024)) return false;
+    int R = 0, ncb = 0;
+    headconv_plan(1, grid, N, N, D, false, false, true, &R, &ncb);
+    return R > 0;
+}
+
 // a.R <= 0: planned here. dec != nullptr: the fused tail (logits + decode) behind a 3x3 layer.
 hipError_t launch_headconv(HeadConvArgs a, const DecodeArgs* dec, hipStream_t st) {
-    const bool halo = a.conv3x3 != 0, tail = dec != nullptr;
-    if (a.B < 1 || !a.in || !a.W || !a.bias || !a.out) return hipErrorInvalidValue;
+    const bool halo = a.conv3x3 != 0, tail = dec != nullptr, ln = a.xh != nullptr;
+    if (a.B < 1 || (!a.in && !ln) || !a.W || !a.bias || !a.out) return hipErrorInvalidValue;
     if (!headconv_supported(a.grid, a.C, a.N, a.K, halo)) return hipErrorInvalidValue;
+    if (ln && (halo || !a.xl || !a.ln_g || !a.ln_b || a.in_stride < a.in_off + a.grid * a.grid || a.in_off < 0 ||
+               !headconv_ln_supported(a.grid, a.N, a.K)))
+        return hipErrorInvalidValue;
     if (halo && (!a.zeros || a.ldin < a.C)) return hipErrorInvalidValue;
     if (tail && (!halo || !a.band_cnt || !a.band_best || !dec->w4 || !dec->b4 || !dec->head_out || !dec->hann || !dec->states ||
                  !dec->results || !dec->out || dec->ns != a.grid * a.grid || dec->B != a.B || dec->grid != a.grid))
         return hipErrorInvalidValue;
     int R = a.R, ncb = a.ncb;
-    if (R <= 0 || ncb <= 0) headconv_plan(a.B, a.grid, a.C, a.N, a.K, halo, tail, &R, &ncb);
+    if (R <= 0 || ncb <= 0) headconv_plan(a.B, a.grid, a.C, a.N, a.K, halo, tail, ln, &R, &ncb);
+    if (R <= 0) return hipErrorInvalidValue;
     if (R > a.grid) R = a.grid;
     const int BN = 64 * ncb, mbmax = (R * a.grid + 15) / 16;
     if (mbmax > HC_MBMAX || a.N % BN || (tail && BN != a.N)) return hipErrorInvalidValue;
     a.R = R; a.ncb = ncb;
     a.bands = (a.grid + R - 1) / R;
     a.mbe_max = (mbmax + 1) & ~1;
-    const int BK = halo ? a.C : 64, rowb = BK * 2, rpp = 1024 / rowb;
-    const size_t himg = halo ? (size_t)(((R + 2) * (a.grid + 2) + rpp - 1) / rpp) * rpp * rowb : 0;
-    const size_t stage = (halo ? 0 : (size_t)a.mbe_max * 16 * rowb) + (size_t)BN * rowb;
-    const size_t ring = (halo ? 3 : 4) * stage;
-    const size_t otile = (size_t)mbmax * 16 * (BN * 2 + 16);
-    size_t smem = himg + std::max(ring, std::max(otile, (size_t)8192));
-    // the fused tail's hand-off (write-through stores, ticket, sc1 loads in place of an acquire) is the form the MI355X
-    // guide measured with ONE workgroup per CU: small models would fit several, so the tail asks for more than half a
-    // CU's LDS (as the 256x256 GEMM's row-panel hand-off has by construction)
-    if (tail) smem = std::max(smem, (size_t)84 * 1024);
-    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    const int BK = halo ? a.C : 64;
+    const size_t smem = headconv_lds(a.grid, a.C, a.N, a.K, halo, tail, ln, R, ncb);
+    if (!smem) return hipErrorInvalidValue;
     const int wgs = a.B * a.bands * (a.N / BN);
     DecodeArgs d{};
     if (dec) d = *dec;
@@ -793,6 +873,12 @@ hipError_t launch_headconv(HeadConvArgs a, const DecodeArgs* dec, hipStream_t st
         return tail ? headconv_launch_mb<64, 1, true, true>(mb, a, d, wgs, smem, st)
                     : headconv_launch_mb<64, 1, true, false>(mb, a, d, wgs, smem, st);
     }
+    if (ln && a.K == 768)
+        return ncb == 2 ? headconv_launch_mb<64, 2, false, false, 3>(mb, a, d, wgs, smem, st)
+                        : headconv_launch_mb<64, 1, false, false, 3>(mb, a, d, wgs, smem, st);
+    if (ln)
+        return ncb == 2 ? headconv_launch_mb<64, 2, false, false, 4>(mb, a, d, wgs, smem, st)
+                        : headconv_launch_mb<64, 1, false, false, 4>(mb, a, d, wgs, smem, st);
     return ncb == 2 ? headconv_launch_mb<64, 2, false, false>(mb, a, d, wgs, smem, st)
                     : headconv_launch_mb<64, 1, false, false>(mb, a, d, wgs, smem, st);
 }

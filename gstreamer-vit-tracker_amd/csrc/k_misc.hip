@@ -84,21 +84,11 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
     r = live ? r : rows - 1;                  // idle half-waves redo the last row, store nothing
     const size_t in_row = (size_t)(r / group) * in_stride + in_off + (r % group);
     f32x4_t v[NCH][2];
-    float sum = 0.0f;
     if constexpr (SPLIT) {
         const u32x4_t* hr = reinterpret_cast<const u32x4_t*>(xh + in_row * D);
         const u32x4_t* lr = reinterpret_cast<const u32x4_t*>(xl + in_row * D);
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const u32x4_t h = hr[l32 + 32 * j], l = lr[l32 + 32 * j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float even = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-                const float odd = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
-                v[j][e >> 1][(e & 1) * 2] = even;
-                v[j][e >> 1][(e & 1) * 2 + 1] = odd;
-            }
-        }
+        for (int j = 0; j < NCH; ++j) ln_unpack_split(hr[l32 + 32 * j], lr[l32 + 32 * j], v[j]);
     } else {
         const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + in_row * D);
 #pragma unroll
@@ -109,51 +99,14 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
     }
     // gamma / beta do not depend on the row: fetched together with it, not after the two reductions
     // (one dependent memory round trip less - what a launch of a few hundred rows is made of)
-    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
-    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
-    f32x4_t gq[NCH][2], bq[NCH][2];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c = l32 + 32 * j;
-        gq[j][0] = g4[2 * c]; gq[j][1] = g4[2 * c + 1];
-        bq[j][0] = b4[2 * c]; bq[j][1] = b4[2 * c + 1];
-    }
-    // hipcc otherwise sinks these loads back behind the reductions: pin the values here, all loads issued
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        asm volatile("" : "+v"(gq[j][0]), "+v"(gq[j][1]), "+v"(bq[j][0]), "+v"(bq[j][1]) : : "memory");
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sum += v[j][0][e] + v[j][1][e];
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)D;
-    float sq = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[j][h][e] -= mean;
-                sq += v[j][h][e] * v[j][h][e];
-            }
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+    LnCoef<NCH> k;
+    ln_load_coef<NCH>(gamma, beta, l32, k);
+    uint4 o[NCH];
+    ln_row<NCH>(v, k, D, eps, o);
     uint4* yr = reinterpret_cast<uint4*>(y + (size_t)r * D);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c = l32 + 32 * j;
-        const f32x4_t g0 = gq[j][0], g1 = gq[j][1], b0 = bq[j][0], b1 = bq[j][1];
-        uint4 o;
-        o.x = pack_bf16x2((v[j][0][0] * rstd) * g0[0] + b0[0], (v[j][0][1] * rstd) * g0[1] + b0[1]);
-        o.y = pack_bf16x2((v[j][0][2] * rstd) * g0[2] + b0[2], (v[j][0][3] * rstd) * g0[3] + b0[3]);
-        o.z = pack_bf16x2((v[j][1][0] * rstd) * g1[0] + b1[0], (v[j][1][1] * rstd) * g1[1] + b1[1]);
-        o.w = pack_bf16x2((v[j][1][2] * rstd) * g1[2] + b1[2], (v[j][1][3] * rstd) * g1[3] + b1[3]);
-        if (live) yr[c] = o;
-    }
+    for (int j = 0; j < NCH; ++j)
+        if (live) yr[l32 + 32 * j] = o[j];
 }
 
 template <bool SPLIT>

@@ -211,8 +211,15 @@ struct HeadConvArgs {
     float* band_best;           // fused tail only: [B][bands][2] each band's argmax candidate (response, cell), bands <= grid
     int bands, mbe_max;         // filled in by the launcher
     unsigned long long* dbg;    // diagnostic builds only (VT_STAMPS): per-wave cycle sums [wgs][8][4]
+    // 1x1 layer with the final LayerNorm inside (xh != nullptr; `in` is ignored): the layer's input row (b, cell) is
+    // LayerNorm(xh + xl)[b * in_stride + in_off + cell][0..K) with gamma ln_g, beta ln_b
+    const bf16_t *xh, *xl;
+    const float *ln_g, *ln_b;
+    float ln_eps;
+    int in_stride, in_off;
 };
 bool headconv_supported(int grid, int C, int N, int K, bool conv3x3);
+bool headconv_ln_supported(int grid, int N, int D);
 hipError_t headconv_prepare();     // once per device, before the first launch / any stream capture
 // dec != nullptr (3x3 layers only): the 5-logit layer, the score window, the argmax and the box decode run inside
 // the same launch (dec->t3 is ignored: the logits are computed from the layer's own output tile)
@@ -234,4 +241,94 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const f32v2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
+}
+
+// ---- one LayerNorm row by half a wave (D = 256 * NCH) -------------------------------------------
+// Lane l32 of the half-wave owns the 8-float chunks c = l32 + 32 j, j < NCH. Two-pass variance; the sums run
+// over a lane's chunks in ascending order, then over the 32 lanes as an xor butterfly (16, 8, 4, 2, 1). The ONE
+// definition of this arithmetic: the LayerNorm kernel (k_misc.hip) and the head's first layer, which normalises
+// its band's rows itself (k_head.hip), produce the same bits by construction.
+// Sum over the 32 lanes of a half-wave, every lane gets the total: the xor butterfly 16, 8, 4, 2, 1 in registers -
+// v_permlane16_swap (odd 16-lane rows of one operand <-> even rows of the other: both copies of v, so a lane ends up
+// holding its own and its xor-16 partner's value), row_ror:8, two masked row shifts by 4 (DPP has no xor-4 pattern:
+// banks 0 / 2 of a row take lane + 4, banks 1 / 3 lane - 4), two quad_perms. Same partners in the same order as
+// "for (off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off)" and therefore the same bits (tools/dpp_xor_check.hip), without
+// that form's five dependent LDS round trips (ds_bpermute) per sum.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    // inline asm, not __builtin_amdgcn_permlane16_swap: on float operands hipcc (ROCm 7.2) adds the swap's FIRST result to
+    // itself (the integer form compiles correctly; tools/dpp_xor_check.hip caught it). s_nop: VALU write -> permlane read
+    // and permlane write -> VALU read wait states, which the compiler cannot see inside the asm.
+    float lo, hi;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1"
+                 : "=&v"(lo), "=&v"(hi) : "v"(v));
+    v = lo + hi;
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));       // row_ror:8
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);                       // row_shl:4 -> banks 0, 2
+    t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);                           // row_shr:4 -> banks 1, 3
+    v += __builtin_bit_cast(float, t);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+    return v;
+}
+
+template <int NCH>
+struct LnCoef { f32x4_t g[NCH][2], b[NCH][2]; };
+
+template <int NCH>
+__device__ __forceinline__ void ln_load_coef(const float* gamma, const float* beta, int l32, LnCoef<NCH>& k) {
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
+    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = l32 + 32 * j;
+        k.g[j][0] = g4[2 * c]; k.g[j][1] = g4[2 * c + 1];
+        k.b[j][0] = b4[2 * c]; k.b[j][1] = b4[2 * c + 1];
+    }
+    // hipcc otherwise sinks these loads behind the row's reductions: pin the values here, all loads issued
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        asm volatile("" : "+v"(k.g[j][0]), "+v"(k.g[j][1]), "+v"(k.b[j][0]), "+v"(k.b[j][1]) : : "memory");
+}
+
+// x = hi + lo of the split residual stream: 8 values of a chunk from the two 16-B pieces
+__device__ __forceinline__ void ln_unpack_split(const u32x4_t h, const u32x4_t l, f32x4_t (&v)[2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float even = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+        const float odd = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
+        v[e >> 1][(e & 1) * 2] = even;
+        v[e >> 1][(e & 1) * 2 + 1] = odd;
+    }
+}
+
+// v: the row's values of this lane (overwritten); o[j]: the normalised chunk l32 + 32 j as 8 bf16
+template <int NCH>
+__device__ __forceinline__ void ln_row(f32x4_t (&v)[NCH][2], const LnCoef<NCH>& k, int D, float eps, uint4 (&o)[NCH]) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += v[j][0][e] + v[j][1][e];
+    sum = half_wave_sum(sum);
+    const float mean = sum / (float)D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][h][e] -= mean;
+                sq += v[j][h][e] * v[j][h][e];
+            }
+    sq = half_wave_sum(sq);
+    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4_t g0 = k.g[j][0], g1 = k.g[j][1], b0 = k.b[j][0], b1 = k.b[j][1];
+        o[j].x = pack_bf16x2((v[j][0][0] * rstd) * g0[0] + b0[0], (v[j][0][1] * rstd) * g0[1] + b0[1]);
+        o[j].y = pack_bf16x2((v[j][0][2] * rstd) * g0[2] + b0[2], (v[j][0][3] * rstd) * g0[3] + b0[3]);
+        o[j].z = pack_bf16x2((v[j][1][0] * rstd) * g1[0] + b1[0], (v[j][1][1] * rstd) * g1[1] + b1[1]);
+        o[j].w = pack_bf16x2((v[j][1][2] * rstd) * g1[2] + b1[2], (v[j][1][3] * rstd) * g1[3] + b1[3]);
+    }
 }

@@ -190,7 +190,11 @@ struct Engine {
     unsigned host_seq = 0, host_collected = 0;   // pipelined passes enqueued / collected
     unsigned host_redos = 0;                      // passes redone because a speculative window missed
     float margin = 0.75f;                         // speculative enlargement of the crop side
-    bool head_band_kernel = true;                 // false: the head as implicit GEMMs + head_out + decode (A/B, tests)
+    int head_band_kernel = 2;                     // 0: the head as implicit GEMMs + head_out + decode (A/B, tests);
+                                                  // 1: band kernels behind the LayerNorm kernel; 2: + the final LayerNorm
+                                                  // inside the 1x1 layer's kernel where the shape allows it (default)
+    bool feat_in_head = false;                    // the passes do not write d_feat (recomputed when read)
+    hipError_t final_layernorm();
     int host_zero_copy = 0;                       // vt_config.host_zero_copy: 0 auto (single-stream engines), 1 always, -1 never
     float success_threshold = 0.2f;
     std::vector<int> h_initialized;
@@ -616,12 +620,14 @@ int Engine::run_pass(Profiler* prof) {
         }
         tap(1 + l);
     }
-    // final LayerNorm on the search tokens only, compacted to [B*ns][D]
-    L("layernorm", 0, (double)Ms * D * 6, [&] {
-        return launch_layernorm_split(d_xh, d_xl, (const float*)find("norm_g")->ptr,
-                                      (const float*)find("norm_b")->ptr, d_feat, Ms, D, d.ns, d.ntok,
-                                      d.nt, d.ln_eps, stream);
-    });
+    // final LayerNorm on the search tokens only, compacted to [B*ns][D] - as a launch of its own unless the head's
+    // first layer normalises its rows itself (k_head.hip, LNC)
+    const bool band = head_band_kernel && headconv_supported(d.gs, d.C, d.C, 9 * d.C, true) &&
+                      headconv_supported(d.gs, d.C, d.C, D, false);
+    const bool ln_fused = band && head_band_kernel >= 2 && headconv_ln_supported(d.gs, d.C, D);
+    feat_in_head = ln_fused;
+    if (!ln_fused)
+        L("layernorm", 0, (double)Ms * D * 6, [&] { return final_layernorm(); });
     // centre head: 1x1 conv, three 3x3 convs, then the f32 5-logit layer + decode. On the band kernel of
     // k_head.hip (the A image of a band resident in LDS, logits + decode fused behind the last layer: 4 launches)
     // where the shape allows it, else as implicit GEMMs on the 4-wave kernel + head_out + decode (6 launches).
@@ -633,8 +639,6 @@ int Engine::run_pass(Profiler* prof) {
     dec.out = (const PassOut*)(d_frames + B);
     dec.B = B; dec.ns = d.ns; dec.grid = d.gs; dec.C = d.C;
     dec.success_threshold = success_threshold;
-    const bool band = head_band_kernel && headconv_supported(d.gs, d.C, d.C, 9 * d.C, true) &&
-                      headconv_supported(d.gs, d.C, d.C, D, false);
     bf16_t* cur = d_ta;
     bf16_t* nxt = d_tb;
     if (band) {
@@ -642,7 +646,13 @@ int Engine::run_pass(Profiler* prof) {
         h.in = d_feat; h.ldin = D; h.W = (const bf16_t*)find("head.w0")->ptr; h.ldw = D;
         h.bias = (const float*)find("head.b0")->ptr; h.out = d_ta; h.ldout = d.C; h.zeros = d_zeros;
         h.B = B; h.grid = d.gs; h.C = d.C; h.N = d.C; h.K = D; h.conv3x3 = 0;
-        L(prof ? "head_conv1x1" : "", 2.0 * Ms * d.C * D, 2.0 * ((double)Ms * D + (double)d.C * D + (double)Ms * d.C),
+        if (ln_fused) {
+            h.in = nullptr;
+            h.xh = d_xh; h.xl = d_xl; h.ln_g = (const float*)find("norm_g")->ptr; h.ln_b = (const float*)find("norm_b")->ptr;
+            h.ln_eps = d.ln_eps; h.in_stride = d.ntok; h.in_off = d.nt;
+        }
+        L(prof ? (ln_fused ? "head_ln_conv1x1" : "head_conv1x1") : "", 2.0 * Ms * d.C * D,
+          2.0 * ((double)Ms * D * (ln_fused ? 2 : 1) + (double)d.C * D + (double)Ms * d.C),
           [&] { return launch_headconv(h, nullptr, stream); });
         for (int k = 1; k <= 3; ++k) {
             const std::string wn = "head.w" + std::to_string(k), bn = "head.b" + std::to_string(k);
@@ -682,6 +692,11 @@ int Engine::run_pass(Profiler* prof) {
     if (lerr != hipSuccess)
         return set_err(VT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
     return VT_OK;     // results and states reach the host through the decode kernel's own stores (PassOut)
+}
+
+hipError_t Engine::final_layernorm() {
+    return launch_layernorm_split(d_xh, d_xl, (const float*)find("norm_g")->ptr, (const float*)find("norm_b")->ptr, d_feat,
+                                  (int)((size_t)B * d.ns), d.D, d.ns, d.ntok, d.nt, d.ln_eps, stream);
 }
 
 int Engine::capture_graph(int tier) {
@@ -1214,7 +1229,7 @@ int vt_group_set_tuning(vt_group* g, const char* key, int value) try {
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     const std::string k = key;
-    if (k == "head_band") e->head_band_kernel = value != 0;
+    if (k == "head_band") e->head_band_kernel = value < 0 ? 2 : value;   // 0 / 1 / 2, see Engine::head_band_kernel
     else if (k == "crop_tier") e->crop_tier_forced = value;      // < 0: chosen per pass from the known boxes (default)
     else return set_err(VT_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
     // the captured passes hold the old choice: drop them, the next pass captures again
@@ -1332,6 +1347,10 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
     const std::string n(name);
     const size_t b = (size_t)stream;
     if (n == "patches") return copy_out_bf16(e->d_patches + b * d.ntok * d.kpad, (int64_t)d.ntok * d.kpad, out, capacity);
+    if (n == "feat" && e->feat_in_head) {       // the pass normalised the rows inside the head's first kernel: same arithmetic, now
+        HIPCHK(e->final_layernorm());        // as a launch (the residual stream of the last pass is still in place)
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     if (n == "feat") return copy_out_bf16(e->d_feat + b * d.ns * d.D, (int64_t)d.ns * d.D, out, capacity);
     if (n == "attn") return copy_out_bf16(e->d_attn + b * d.ntok * d.D, (int64_t)d.ntok * d.D, out, capacity);
     if (n == "head_t3") return copy_out_bf16(e->d_tb + b * d.ns * d.C, (int64_t)d.ns * d.C, out, capacity);
@@ -2323,6 +2342,85 @@ int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, con
                 med(col[0][0]), med(col[0][1]), med(col[0][2]), med(col[0][3]), med(col[1][0]), med(col[1][1]), med(col[1][2]), med(col[1][3]));
     }
 #endif
+    return VT_OK;
+} VT_NOTHROW_INT
+
+// The head's first layer with the final LayerNorm: out[b * ns + cell][n] = ReLU(LayerNorm(xh + xl)[b * ntok + off + cell] . w[n] + bias[n])
+// as bf16. fused != 0: one launch (the band kernel normalises its rows itself); fused == 0: the LayerNorm kernel, then the
+// band kernel on its output - the form the fused one must reproduce bit for bit. xh == nullptr: synthetic operands (timing).
+int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl, const float* gamma, const float* beta,
+                           float eps, int ntok, int off, const uint16_t* w, const float* bias, float* out, int B, int grid,
+                           int D, int N, int fused, int R, int ncb, int iters, float* us_out) try {
+    const int ns = grid * grid;
+    if (B < 1 || grid < 1 || off < 0 || ntok < off + ns || (xh && (!xl || !gamma || !beta || !w || !bias)))
+        return set_err(VT_ERR_INVALID_ARG, "bad argument");
+    if (!headconv_ln_supported(grid, N, D))
+        return set_err(VT_ERR_INVALID_ARG, "shape not supported by the band kernel with the LayerNorm inside");
+    if (int rc = check_device(device_id)) return rc;
+    DEVICE_SCOPE(device_id);
+    HIPCHK(headconv_prepare());
+    const size_t Mx = (size_t)B * ntok, M = (size_t)B * ns;
+    DevBuf dh, dl, dg, dbt, dw, db, dfeat, dout;
+    HIPCHK(dh.alloc(Mx * D * 2)); HIPCHK(dl.alloc(Mx * D * 2)); HIPCHK(dg.alloc((size_t)D * 4)); HIPCHK(dbt.alloc((size_t)D * 4));
+    HIPCHK(dw.alloc((size_t)N * D * 2)); HIPCHK(db.alloc((size_t)N * 4)); HIPCHK(dfeat.alloc(M * D * 2)); HIPCHK(dout.alloc(M * N * 2));
+    if (xh) {
+        HIPCHK(hipMemcpy(dh.p, xh, Mx * D * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dl.p, xl, Mx * D * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dg.p, gamma, (size_t)D * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dbt.p, beta, (size_t)D * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dw.p, w, (size_t)N * D * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<bf16_t> hx(Mx * D), hw((size_t)N * D);
+        std::vector<float> ones((size_t)D, 1.0f);
+        uint32_t seed = 4242u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (bf16_t)(0x3c00u + ((seed >> 9) & 0x3ffu) + ((seed >> 3) & 0x8000u)); };
+        for (auto& v : hx) v = rnd();
+        for (auto& v : hw) v = rnd();
+        HIPCHK(hipMemcpy(dh.p, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(dl.p, 0, Mx * D * 2));
+        HIPCHK(hipMemcpy(dg.p, ones.data(), (size_t)D * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(dbt.p, 0, (size_t)D * 4));
+        HIPCHK(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(db.p, 0, (size_t)N * 4));
+    }
+    HeadConvArgs h{};
+    h.W = (const bf16_t*)dw.p; h.ldw = D; h.bias = (const float*)db.p; h.out = (bf16_t*)dout.p; h.ldout = N;
+    h.B = B; h.grid = grid; h.C = N; h.N = N; h.K = D; h.conv3x3 = 0; h.R = R; h.ncb = ncb;
+    if (fused) {
+        h.xh = (const bf16_t*)dh.p; h.xl = (const bf16_t*)dl.p; h.ln_g = (const float*)dg.p; h.ln_b = (const float*)dbt.p;
+        h.ln_eps = eps; h.in_stride = ntok; h.in_off = off;
+    } else {
+        h.in = (const bf16_t*)dfeat.p; h.ldin = D;
+    }
+    auto run = [&]() -> hipError_t {
+        if (!fused) {
+            hipError_t e = launch_layernorm_split((const bf16_t*)dh.p, (const bf16_t*)dl.p, (const float*)dg.p, (const float*)dbt.p,
+                                                  (bf16_t*)dfeat.p, (int)M, D, ns, ntok, off, eps, nullptr);
+            if (e != hipSuccess) return e;
+        }
+        return launch_headconv(h, nullptr, nullptr);
+    };
+    HIPCHK(run());
+    HIPCHK(hipDeviceSynchronize());
+    if (out) {
+        std::vector<bf16_t> tmp(M * N);
+        HIPCHK(hipMemcpy(tmp.data(), dout.p, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) { uint32_t u = ((uint32_t)tmp[i]) << 16; memcpy(out + i, &u, 4); }
+    }
+    if (iters > 0 && us_out) {
+        for (int i = 0; i < 3; ++i) HIPCHK(run());
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) HIPCHK(run());
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *us_out = ms * 1000.0f / iters;
+    }
     return VT_OK;
 } VT_NOTHROW_INT
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 4   /* 4: vt_config.host_zero_copy (a former reserved slot: zero = the old default for single trackers), vt_group_set_tuning, vt_op_headconv_bf16 - additions only, a host built against 3 keeps working; 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
+#define VT_ABI_VERSION 4   /* 4: vt_config.host_zero_copy (a former reserved slot: zero = the old default for single trackers), vt_group_set_tuning, vt_op_headconv_bf16, vt_op_headconv_ln_bf16 - additions only, a host built against 3 keeps working; 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
 
 typedef enum vt_status {
     VT_OK = 0,
@@ -358,8 +358,9 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
  * patch embedding and after every encoder block (for stage-level parity tests). */
 int vt_group_enable_taps(vt_group* g, int enable);
 /* Diagnostics (A/B measurements and parity tests of alternative kernels; results are the same quantity either
- * way): key "head_band": 1 (default) = the head's convolutions on the band kernel with the logits and the decode
- * fused behind the last layer, 0 = implicit GEMMs + head_out + decode launches; key "crop_tier": >= 0 forces the crop
+ * way): key "head_band": 2 (default; any negative value selects it) = the head's convolutions on the band kernel, the
+ * final LayerNorm inside the first layer's launch and the logits and the decode behind the last layer's, 1 = the same
+ * with the LayerNorm as a launch of its own, 0 = implicit GEMMs + head_out + decode launches; key "crop_tier": >= 0 forces the crop
  * kernel's LDS buffer tier (0: 16 KiB, 1: 32 KiB, 2: 64 KiB), < 0 (default) = chosen per pass from the boxes the host
  * knows. Not while a pipelined pass is outstanding. */
 int vt_group_set_tuning(vt_group* g, const char* key, int value);
@@ -419,6 +420,14 @@ int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w,
  * microseconds per launch. */
 int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
                         int B, int grid, int Cin, int N, int conv3x3, int R, int ncb, int iters, float* us_out);
+/* The head's first (1x1) layer with the final LayerNorm in front of it: out[b*grid*grid + cell][n] =
+ * relu(LayerNorm(xh + xl)[b*ntok + off + cell] . w[n] + bias[n]); xh / xl [B*ntok][D] the bf16 pair of the residual
+ * stream, gamma / beta [D], w [N][D], D = 768 or 1024. fused != 0: ONE launch - the band kernel normalises its band's
+ * rows itself (what the engine runs); fused == 0: the LayerNorm kernel, then the band kernel on its output - the fused
+ * form reproduces it bit for bit. R / ncb / iters / us_out / out as above; xh == NULL: synthetic operands (timing). */
+int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl, const float* gamma, const float* beta,
+                           float eps, int ntok, int off, const uint16_t* w, const float* bias, float* out, int B, int grid,
+                           int D, int N, int fused, int R, int ncb, int iters, float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
  * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
  * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;

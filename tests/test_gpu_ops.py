@@ -448,6 +448,42 @@ def test_head_band_kernel_conv1x1(gpu, B, grid, K, N, R, ncb):
                           gpu.op_gemm_bf16(ar, wr, br, epilogue=3, cfg=2))
 
 
+@pytest.mark.parametrize("B,grid,D,N,ntok,off,R,ncb", [
+    (1, 24, 768, 128, 720, 144, 0, 0), (30, 24, 768, 128, 720, 144, 0, 0), (2, 24, 768, 128, 720, 144, 3, 2),
+    (2, 24, 768, 128, 720, 144, 2, 1), (3, 24, 768, 64, 600, 24, 1, 1), (3, 16, 768, 128, 320, 64, 0, 0),
+    (2, 16, 768, 128, 320, 64, 4, 2), (2, 15, 768, 128, 230, 5, 2, 2), (2, 15, 768, 128, 230, 5, 3, 1),
+    (2, 28, 1024, 128, 980, 196, 0, 0), (2, 28, 1024, 128, 980, 196, 2, 2), (9, 28, 1024, 128, 980, 196, 1, 1)])
+def test_head_band_kernel_with_the_final_layernorm_inside(gpu, B, grid, D, N, ntok, off, R, ncb):
+    """k_head.hip, LNC: the 1x1 layer's workgroup normalises its band's rows of the split residual stream itself (resident
+    A image, weights through the ring). Bit-identical to the LayerNorm kernel followed by the band kernel - the same
+    row arithmetic by construction (ln_row, vt_common.hpp) - on every plan incl. a short last band (grid 15) and an A
+    image that is not a whole number of KiB; and within bf16 rounding of a float64 LayerNorm + product."""
+    rng = np.random.default_rng(B * 7 + grid + D + N + R + ncb)
+    x = (rng.standard_normal((B * ntok, D)) * rng.uniform(0.2, 3.0, size=(B * ntok, 1)) +
+         rng.standard_normal((B * ntok, 1))).astype(np.float32)
+    xh = _bits(gpu, x)
+    xhf = gpu.weights.bf16_bits_to_f32(xh)
+    xl = _bits(gpu, x - xhf)
+    xlf = gpu.weights.bf16_bits_to_f32(xl)
+    gamma = (1.0 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    wb, w = _rand_bf16(gpu, rng, (N, D), 0.05)
+    bias = (0.3 * rng.standard_normal(N)).astype(np.float32)
+    two = gpu.op_headconv_ln(xh, xl, gamma, beta, wb, bias, B, grid, ntok, off, fused=False, R=R, ncb=ncb)
+    for _ in range(2):
+        one = gpu.op_headconv_ln(xh, xl, gamma, beta, wb, bias, B, grid, ntok, off, fused=True, R=R, ncb=ncb)
+        assert np.array_equal(one, two)
+    ns = grid * grid
+    rows = (np.arange(B)[:, None] * ntok + off + np.arange(ns)[None, :]).ravel()
+    xs = xhf[rows].astype(np.float64) + xlf[rows]
+    mu = xs.mean(1, keepdims=True)
+    var = ((xs - mu) ** 2).mean(1, keepdims=True)
+    y = bf16_round(((xs - mu) / np.sqrt(var + 1e-6) * gamma + beta).astype(np.float32))
+    ref = np.maximum(y.astype(np.float64) @ w.astype(np.float64).T + bias, 0)
+    # a LayerNorm output one bf16 step off (float32 vs float64 at a rounding boundary) moves a sum of D products by < 1e-2
+    assert np.all(np.abs(one - ref) <= np.abs(ref) * 2 ** -8 + 2e-2)
+
+
 @pytest.mark.parametrize("tokens,B", [(720, 30), (980, 9), (100, 70)])
 def test_gemm256_persistent_qkv_and_activation_full_chip(gpu, tokens, B):
     """config 19 (persistent workgroups, wave-private epilogue, next tile's prologue in flight under

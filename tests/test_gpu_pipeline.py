@@ -908,3 +908,33 @@ def test_head_band_kernel_equals_the_separate_launches(gpu, cfg, B):
         sa, sb = ga.read_state(B - 1), gb.read_state(B - 1)
         assert sa["frames_done"] == sb["frames_done"] == 6 and sa["last_idx"] == sb["last_idx"]
         del ga, gb
+
+
+@pytest.mark.parametrize("cfg,B", [("cfg3", 1), ("cfg3", 30), ("cfg2", 5), ("cfg5", 2)])
+def test_final_layernorm_inside_the_heads_first_kernel_changes_no_value(gpu, cfg, B):
+    """the default pass (the band kernel of the head's 1x1 layer normalises its rows itself: no LayerNorm launch, "feat"
+    never written by the pass) against the same engine with the LayerNorm kernel in front (vt_group_set_tuning
+    "head_band" 1): every head tensor, the logits, scores, boxes and stream states bit-identical over a short closed
+    loop, graph replay and eager; "feat" read from the default engine (recomputed on demand from the residual stream
+    the pass left) equals the tensor the other engine's pass wrote."""
+    name = {"cfg3": "vitb16_t192_s384", "cfg2": "vitb16_t128_s256", "cfg5": "vitl14_t196_s392"}[cfg]
+    weights = gpu.weights.ensure_weights(name)
+    w, h = 1920, 1080
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=43)
+    for use_graph in (True, False):
+        ga = gpu.Group(weights, n_streams=B, use_graph=use_graph)
+        gb = gpu.Group(weights, n_streams=B, use_graph=use_graph)
+        gb.set_tuning("head_band", 1)
+        f0 = gpu.NV12Frame(sc.frame_nv12(0), w, h)
+        for i in range(B):
+            ga.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+            gb.init_host(i, f0, gpu.BBox.new(*sc.gt_box(0)))
+        for t in range(4):
+            f = gpu.NV12Frame(sc.frame_nv12(t), w, h)
+            ra, rb = ga.update_host([f] * B), gb.update_host([f] * B)
+            assert [(r.bbox, r.success, r.score) for r in ra] == [(r.bbox, r.success, r.score) for r in rb], t
+            for i in (0, B - 1):
+                for tensor in ("head_t3", "head_out", "feat"):
+                    assert np.array_equal(ga.read_tensor(tensor, i), gb.read_tensor(tensor, i)), (t, i, tensor)
+                assert np.array_equal(ga.read_tensor("state", i).view(np.uint32), gb.read_tensor("state", i).view(np.uint32)), (t, i)
+        del ga, gb

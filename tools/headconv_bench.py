@@ -24,3 +24,16 @@ for B in Bs:
                 us = vt.op_headconv_bench(B, grid, C if conv else D, C, conv, R, ncb, iters=50)
                 row.append(f"R{R}n{ncb} {us:6.1f}")
         print(f"B={B:2d} {name} M={M:5d} K={K:4d} | " + " | ".join(row), flush=True)
+    # the 1x1 layer with the final LayerNorm in front: two launches (LayerNorm kernel + band kernel) against one
+    if D in (768, 1024):
+        ntok, off = grid * grid + (grid // 2) ** 2, (grid // 2) ** 2
+        row = [f"two launches {vt.op_headconv_ln_bench(B, grid, D, C, ntok, off, fused=False):6.1f}us",
+               f"one (plan) {vt.op_headconv_ln_bench(B, grid, D, C, ntok, off, fused=True):6.1f}us"]
+        for R in range(1, grid + 1):
+            for ncb in ((2, 1) if C == 128 else (1,)):
+                try:
+                    us = vt.op_headconv_ln_bench(B, grid, D, C, ntok, off, fused=True, R=R, ncb=ncb)
+                except vt.VtError:
+                    continue
+                row.append(f"R{R}n{ncb} {us:6.1f}")
+        print(f"B={B:2d} ln+conv1x1 D={D} | " + " | ".join(row), flush=True)
