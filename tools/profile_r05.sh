@@ -30,6 +30,7 @@ run fc1 python3 tools/one_gemm.py $M 3072 768 2 19 20
 run attn python3 tools/attn_bench.py 3 30
 run conv3 python3 tools/one_headconv.py 30 24 128 128 1 0 0 20
 run conv1 python3 tools/one_headconv.py 30 24 768 128 0 0 0 20
+run lnconv1 python3 tools/one_headconv.py 30 24 768 128 2 0 0 20
 python3 tools/pmc_summary.py $OUT/fc1 gemm256p_kernel $O/r05_dominant_kernel_pmc.json --family gemm_bf16_gelu_256x256pp_n3072k768 \
     --streams 30 --algorithmic-bytes $((M*768*2 + 3072*768*2 + M*3072*2)) --command "python3 tools/one_gemm.py $M 3072 768 2 19 20" > /dev/null
 python3 tools/pmc_summary.py $OUT/attn attention_dma_kernel $O/r05_attention_pmc.json --family attention \
@@ -38,6 +39,8 @@ python3 tools/pmc_summary.py $OUT/conv3 head_conv_kernel $O/r05_head_conv3x3_pmc
     --streams 30 --algorithmic-bytes $((MS*128*2*2 + 128*1152*2)) --command "python3 tools/one_headconv.py 30 24 128 128 1 0 0 20" > /dev/null
 python3 tools/pmc_summary.py $OUT/conv1 head_conv_kernel $O/r05_head_conv1x1_pmc.json --family head_conv1x1 \
     --streams 30 --algorithmic-bytes $((MS*768*2 + MS*128*2 + 128*768*2)) --command "python3 tools/one_headconv.py 30 24 768 128 0 0 0 20" > /dev/null
+python3 tools/pmc_summary.py $OUT/lnconv1 head_conv_kernel $O/r05_head_ln_conv1x1_pmc.json --family head_ln_conv1x1 \
+    --streams 30 --algorithmic-bytes $((MS*768*4 + MS*128*2 + 128*768*2)) --command "python3 tools/one_headconv.py 30 24 768 128 2 0 0 20" > /dev/null
 echo "pmc done"
 find $O -name "*kernel_stats.csv" | head
 fi
