@@ -454,10 +454,12 @@ def run_rank(args):
             "bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
             "traffic_source": traffic_src,
-            "source": "HIP events around every launch of ONE engine's eager instrumented pass "
-                      "(vt_group_profile_device, 5 passes) on the library's own stream, right after the timed "
-                      "region - not the timed hipGraph replays; rocprofv3 kernel-trace averages of the same "
-                      "command (profiles/) agree within 2 %",
+            "source": "HIP events bound to every dispatch (hipExtLaunchKernelGGL start / stop events) of ONE engine's "
+                      "eager instrumented pass (vt_group_profile_device, 5 passes) on the library's own stream, right "
+                      "after the timed region - not the timed hipGraph replays. They read 3-4 us per launch ABOVE "
+                      "the begin -> end durations rocprofv3's kernel trace gives for the same dispatches (same process, "
+                      "profiles/r05_trace_cfg3_30x1_bench_line.json against r05_bench_cfg3_30x1_kernel_stats.csv: 97.3 "
+                      "against 93.6 us): `achieved` is the conservative one of the two",
             "launches_per_step": dom["launches"],
             "avg_launch_us": dom["ms"] / max(dom["launches"], 1) * 1e3,
             "flops_per_launch": dom["flops"] / max(dom["launches"], 1),

@@ -918,40 +918,40 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
     if (mode >= 2 && npad % 64 != 0) return hipErrorInvalidValue;
     if (mode >= 3 && tokens % 4 != 0) return hipErrorInvalidValue;
     if (mode == 0) {
-        hipLaunchKernelGGL(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
+        vt_launch(attention_kernel<true>, dim3(nqb, H, B), dim3(256), 0, st, qk, vt, out,
                            tokens, H, npad);
     } else if (mode == 1) {
-        hipLaunchKernelGGL(attention_kernel<false>, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk,
+        vt_launch(attention_kernel<false>, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk,
                            vt, out, tokens, H, npad);
     } else if (mode == 2) {
-        hipLaunchKernelGGL(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
+        vt_launch(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
     } else if (mode == 3) {
         // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc
         // then spills (100 B of scratch) sits in the rare second pass only (checked in the ISA)
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<0, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 7) {               // tuning only: mode 3 with the row sums from a P.V MFMA against ones
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 0>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<0, 3, 3, 0>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 6) {               // tuning only: mode 3 without the unchecked first pass (round 2's kernel)
-        hipLaunchKernelGGL((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
-        hipLaunchKernelGGL((attention_dma_kernel<1, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<1, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 8) {               // tuning: mode 3 with the row sums by 4x4x4 MFMAs (A = ones)
-        hipLaunchKernelGGL((attention_dma_kernel<0, 3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<0, 3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 9) {               // tuning: FOUR workgroups per CU (<= 128 registers, 2-stage ring, sequential halves)
         // with the unchecked first pass and 4x4x4-MFMA row sums: the one structure round 4 left untried
-        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<2, 2, 4, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 10) {              // the same with v_dot2c row sums
-        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<2, 2, 4, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else if (mode == 5) {               // 4 workgroups per CU: 2-stage ring, sequential halves in <= 128 registers
-        hipLaunchKernelGGL((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
+        vt_launch((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad, 0);
     } else {
         return hipErrorInvalidValue;

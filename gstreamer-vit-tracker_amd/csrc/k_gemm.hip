@@ -785,7 +785,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
     if (a.conv_grid > 0 && a.conv_C % BK != 0) return hipErrorInvalidValue;   // a K-tile lies inside one tap
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI, LW>), dim3(tiles),
+    vt_launch((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI, LW>), dim3(tiles),
                        dim3(WVM * WVN * 64 * (LW ? 2 : 1)), smem, st, a);
     return hipGetLastError();
 }

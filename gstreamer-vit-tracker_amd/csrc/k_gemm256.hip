@@ -1315,7 +1315,7 @@ hipError_t prepare_persistent() {
 template <int EPI>
 hipError_t launch_persistent(const GemmArgs& a, hipStream_t st) {
     const int tiles_n = a.N / 256, tiles = ((a.M + 255) / 256) * tiles_n;
-    hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(256), dim3(512), G256P_LDS, st, a, tiles,
+    vt_launch((gemm256p_kernel<EPI>), dim3(256), dim3(512), G256P_LDS, st, a, tiles,
                        g256p_cgw(tiles_n));
     return hipGetLastError();
 }
@@ -1332,8 +1332,8 @@ hipError_t prepare_one() {
 template <int EPI>
 hipError_t launch_one(const GemmArgs& a, int ver, hipStream_t st) {
     const int tiles = ((a.M + 255) / 256) * (a.N / 256);
-    if (ver == 2) hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), dim3(tiles), dim3(512), G256_LDS, st, a);
-    else hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    if (ver == 2) vt_launch((gemm256_kernel<EPI, 2>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    else vt_launch((gemm256_kernel<EPI, 1>), dim3(tiles), dim3(512), G256_LDS, st, a);
     return hipGetLastError();
 }
 

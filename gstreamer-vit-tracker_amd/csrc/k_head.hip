@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256) void head_out_kernel(const bf16_t* __restrict_
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
     if (a.C % 2 != 0) return hipErrorInvalidValue;
     const int rows = a.B * a.ns;
-    hipLaunchKernelGGL(head_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a.t3, a.w4, a.b4, a.head_out,
+    vt_launch(head_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a.t3, a.w4, a.b4, a.head_out,
                        rows, a.C);
-    hipLaunchKernelGGL(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
+    vt_launch(decode_kernel, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -771,7 +771,7 @@ static void headconv_plan(int B, int grid, int C, int N, int K, bool halo, bool 
 
 template <int BK, int NCB, int MB, bool HALO, bool TAIL, int LNC>
 static hipError_t headconv_launch_t(const HeadConvArgs& a, const DecodeArgs& dec, int wgs, size_t smem, hipStream_t st) {
-    hipLaunchKernelGGL((head_conv_kernel<BK, NCB, MB, HALO, TAIL, LNC>), dim3(wgs), dim3(512), smem, st, a, dec);
+    vt_launch((head_conv_kernel<BK, NCB, MB, HALO, TAIL, LNC>), dim3(wgs), dim3(512), smem, st, a, dec);
     return hipGetLastError();
 }
 template <int BK, int NCB, bool HALO, bool TAIL, int LNC = 0>

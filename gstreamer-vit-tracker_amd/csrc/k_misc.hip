@@ -118,7 +118,7 @@ static hipError_t launch_layernorm_any(const float* x, const bf16_t* xh, const b
         dim3 gridw((rows + 7) / 8), block(256);
 #define LNW_CASE(n)                                                                                      \
     case n:                                                                                              \
-        hipLaunchKernelGGL((layernorm_wide_kernel<n, SPLIT>), gridw, block, 0, st, x, xh, xl, gamma, beta, y, \
+        vt_launch((layernorm_wide_kernel<n, SPLIT>), gridw, block, 0, st, x, xh, xl, gamma, beta, y, \
                            rows, D, group, in_stride, in_off, eps);                                      \
         break;
         switch (D / 256) { LNW_CASE(1) LNW_CASE(2) LNW_CASE(3) LNW_CASE(4) }
@@ -128,7 +128,7 @@ static hipError_t launch_layernorm_any(const float* x, const bf16_t* xh, const b
     dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(n)                                                                                       \
     case n:                                                                                              \
-        hipLaunchKernelGGL((layernorm_kernel<n, SPLIT>), grid, block, 0, st, x, xh, xl, gamma, beta, y, rows, \
+        vt_launch((layernorm_kernel<n, SPLIT>), grid, block, 0, st, x, xh, xl, gamma, beta, y, rows, \
                            D, group, in_stride, in_off, eps);                                            \
         break;
     switch (D / 128) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float2* __r
 hipError_t launch_rowstat_finalize(const float2* cstat, float2* rowstat, int M, int nchunk, float eps,
                                    hipStream_t st) {
     if (M <= 0 || nchunk < 1 || nchunk > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((M + 7) / 8), dim3(256), 0, st, cstat, rowstat, M, nchunk, eps);
+    vt_launch(rowstat_finalize_kernel, dim3((M + 7) / 8), dim3(256), 0, st, cstat, rowstat, M, nchunk, eps);
     return hipGetLastError();
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const bf16_t* __res
 hipError_t launch_fold_layernorm(const bf16_t* W, const float* gamma, const float* beta, const float* bias,
                                  bf16_t* Wf, float* colsum, float* cvec, int N, int K, hipStream_t st) {
     if (N <= 0 || K <= 0 || (K & 1)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wf, colsum,
+    vt_launch(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wf, colsum,
                        cvec, N, K);
     return hipGetLastError();
 }

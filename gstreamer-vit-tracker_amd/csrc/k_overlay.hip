@@ -129,7 +129,7 @@ hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, co
                           int n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     dim3 grid((width + 63) / 64, (height + 3) / 4);
-    hipLaunchKernelGGL(overlay_kernel, grid, dim3(256), 0, st, yplane, width, height, stride, d_cmds, n);
+    vt_launch(overlay_kernel, grid, dim3(256), 0, st, yplane, width, height, stride, d_cmds, n);
     return hipGetLastError();
 }
 
@@ -214,6 +214,6 @@ hipError_t launch_overlay_rgb(uint8_t* rgb, int width, int height, int stride, c
                               hipStream_t st) {
     if (n <= 0) return hipSuccess;
     dim3 grid((width + 63) / 64, (height + 3) / 4);
-    hipLaunchKernelGGL(overlay_rgb_kernel, grid, dim3(256), 0, st, rgb, width, height, stride, d_cmds, n);
+    vt_launch(overlay_rgb_kernel, grid, dim3(256), 0, st, rgb, width, height, stride, d_cmds, n);
     return hipGetLastError();
 }

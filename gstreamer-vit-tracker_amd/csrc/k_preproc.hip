@@ -127,14 +127,14 @@ hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, 
         int blocks = (int)((total + 255) / 256);
         if (blocks > 256 * 8) blocks = 256 * 8;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(nv12_to_rgb8_wide_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
+        vt_launch(nv12_to_rgb8_wide_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
         return hipGetLastError();
     }
     const long total = (long)((w + 3) >> 2) * h;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(nv12_to_rgb8_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
+    vt_launch(nv12_to_rgb8_kernel, dim3(blocks), dim3(256), 0, st, nv12, w, h, rgb);
     return hipGetLastError();
 }
 
@@ -525,18 +525,18 @@ hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* 
     // store alignment: a run starts at element c*p*p + py*p + px0 of a row of kpad elements
     if (d.patch % 8 == 0 && d.kpad % 8 == 0 && size % PRE_TILE_W == 0 && size % PRE_TILE_H == 0) {
         dim3 grid((size / PRE_TILE_W) * (size / PRE_TILE_H), nb);   // 64 x 32 output tiles, source staged in LDS
-        if (tier <= 0) hipLaunchKernelGGL(preproc_tile_kernel<PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
-        else if (tier == 1) hipLaunchKernelGGL(preproc_tile_kernel<2 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
-        else hipLaunchKernelGGL(preproc_tile_kernel<4 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
+        if (tier <= 0) vt_launch(preproc_tile_kernel<PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
+        else if (tier == 1) vt_launch(preproc_tile_kernel<2 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
+        else vt_launch(preproc_tile_kernel<4 * PRE_TILE_LDS>, grid, dim3(256), 0, st, PRE_ARGS);
     } else if (d.patch % 8 == 0 && d.kpad % 8 == 0) {          // 16-B stores
         dim3 grid((size * size / 8 + 255) / 256, nb);
-        hipLaunchKernelGGL(preproc_wide_kernel<8>, grid, dim3(256), 0, st, PRE_ARGS);
+        vt_launch(preproc_wide_kernel<8>, grid, dim3(256), 0, st, PRE_ARGS);
     } else if (d.patch % 2 == 0 && d.kpad % 2 == 0) {          // 4-B stores (patch 14)
         dim3 grid((size * size / 2 + 255) / 256, nb);
-        hipLaunchKernelGGL(preproc_wide_kernel<2>, grid, dim3(256), 0, st, PRE_ARGS);
+        vt_launch(preproc_wide_kernel<2>, grid, dim3(256), 0, st, PRE_ARGS);
     } else {
         dim3 grid((size * size + 255) / 256, nb);
-        hipLaunchKernelGGL(preproc_kernel, grid, dim3(256), 0, st, PRE_ARGS);
+        vt_launch(preproc_kernel, grid, dim3(256), 0, st, PRE_ARGS);
     }
 #undef PRE_ARGS
     return hipGetLastError();

@@ -1,6 +1,7 @@
 // vt_common.hpp — types shared by the host engine and the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/vittrack_hip.h"
@@ -224,6 +225,21 @@ hipError_t headconv_prepare();     // once per device, before the first launch /
 // dec != nullptr (3x3 layers only): the 5-logit layer, the score window, the argmax and the box decode run inside
 // the same launch (dec->t3 is ignored: the logits are computed from the layer's own output tile)
 hipError_t launch_headconv(HeadConvArgs a, const DecodeArgs* dec, hipStream_t st);
+
+// ---- kernel launches -----------------------------------------------------------------------------
+// Every kernel of the library is launched through vt_launch. It is hipLaunchKernelGGL, except while the engine's
+// instrumented pass (vt_group_profile_device) has armed a probe on the calling thread: the first launch behind the arming
+// then goes through hipExtLaunchKernelGGL with the probe's two HIP events, which receive the begin and end timestamps of
+// THAT dispatch - the duration rocprofv3's kernel trace reports - instead of the time between two marker packets around
+// it (which adds the dispatch and marker latency, ~4 us per launch on this stack).
+struct LaunchProbe { hipEvent_t start, stop; int launches; };
+extern thread_local LaunchProbe* vt_launch_probe;
+template <typename F, typename... Args>
+inline void vt_launch(F kernel, const dim3& grid, const dim3& block, size_t smem, hipStream_t st, Args... args) {
+    LaunchProbe* pr = vt_launch_probe;
+    if (pr && pr->launches++ == 0) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)smem, st, pr->start, pr->stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, smem, st, args...);
+}
 
 // ---- small device helpers ---------------------------------------------------------------------
 

@@ -100,8 +100,12 @@ struct KernelStat {
     double ms = 0, flops = 0, bytes = 0;
 };
 
+thread_local LaunchProbe* vt_launch_probe = nullptr;
+
 struct Profiler {
-    struct Rec { hipEvent_t a, b; int fam; };
+    // a, b: marker events around the entry's launches; k: the first launch's own begin / end (vt_launch), used when the
+    // entry was exactly one launch
+    struct Rec { hipEvent_t a, b; LaunchProbe k; int fam; };
     std::vector<Rec> recs;
     std::vector<KernelStat> fams;
     int family(const std::string& n) {
@@ -512,8 +516,13 @@ int Engine::run_pass(Profiler* prof) {
             r.fam = prof->family(name);
             (void)hipEventCreate(&r.a);
             (void)hipEventCreate(&r.b);
+            (void)hipEventCreate(&r.k.start);
+            (void)hipEventCreate(&r.k.stop);
+            r.k.launches = 0;
             (void)hipEventRecord(r.a, stream);
+            vt_launch_probe = &r.k;
             lerr = fn();
+            vt_launch_probe = nullptr;
             (void)hipEventRecord(r.b, stream);
             prof->recs.push_back(r);
             prof->fams[r.fam].launches += 1;
@@ -1281,10 +1290,14 @@ int vt_group_profile_device(vt_group* g, const vt_frame* frames, int n, int iter
     HIPCHK(hipStreamSynchronize(e->stream));
     for (auto& r : prof.recs) {
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        // one launch: its own begin -> end; several (or none through vt_launch): the markers around them
+        if (r.k.launches != 1 || hipEventElapsedTime(&ms, r.k.start, r.k.stop) != hipSuccess || ms <= 0.0f)
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
         prof.fams[r.fam].ms += ms;
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.k.start);
+        (void)hipEventDestroy(r.k.stop);
     }
     int k = 0;
     for (auto& f : prof.fams) {
