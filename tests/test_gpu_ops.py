@@ -637,3 +637,23 @@ def test_attention_second_pass_only_where_needed(gpu):
     # bf16 outputs may differ by one unit in the last place, not more
     assert np.all(np.abs(got3[calm] - got6[calm]) <= np.abs(got6[calm]) * 2.0 ** -7 + 1e-6)
     assert np.array_equal(got3, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=3))      # run-to-run identical
+
+
+def test_register_only_half_wave_sum_has_the_butterflys_bits(gpu, tmp_path):
+    """half_wave_sum (vt_common.hpp: v_permlane16_swap + DPP, the two row sums of the final LayerNorm) against the
+    __shfl_xor butterfly it replaced, lane by lane on 4,096 waves of pseudo-random values: the same partners in the same
+    order, so the same bits. Built from tools/dpp_xor_check.hip on the box (the check that caught hipcc adding the swap's
+    first result to itself when the builtin gets bit-cast floats)."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dpp_xor_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", os.path.join(root, "tools", "dpp_xor_check.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of 262144 lanes differ" in r.stdout
