@@ -152,11 +152,23 @@ def main(argv=None):
     run_rank(args)
 
 
+def pin_rank(local: int, world: int) -> dict:
+    """CPU placement of this rank BEFORE numpy / torch / HIP load (their threads inherit the mask): the CPUs of the
+    GPU's NUMA node, sliced between the ranks that share it (gstreamer-vit-tracker_amd/placement.py, loaded by path so
+    that nothing else is imported first)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_vt_placement", os.path.join(ROOT, "gstreamer-vit-tracker_amd", "placement.py"))
+    pl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pl)
+    return pl.apply(local, world)
+
+
 def run_rank(args):
     # dmabuf IPC only on this pool: RCCL's (and torch's) cross-process buffer sharing fails with
     # hipIpcGetMemHandle otherwise. Set before torch / HIP load, so that ranks started by an external
     # `python -m torch.distributed.run ... bench.py --gpus N` get it exactly like the self-launched ones.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    affinity = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
     import numpy as np
     import torch
     import gstreamer_vit_tracker_amd as vt
@@ -170,7 +182,7 @@ def run_rank(args):
                          "its own ranks) or python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     cfg_name, wl_text = WORKLOADS[args.workload]
     if args.dry_run:
-        return dry_run(args, vt, vd, world, rank, cfg_name, wl_text)
+        return dry_run(args, vt, vd, world, rank, cfg_name, wl_text, affinity)
     have = torch.cuda.device_count()
     if have < world:
         raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {have} GPU(s); this run needs {world} devices "
@@ -380,7 +392,10 @@ def run_rank(args):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": wl_text, "vit_config": cfg_name, "frame": f"{fw}x{fh} NV12",
                    "streams_per_gpu": B, "engines_per_gpu": G, "engine_sizes": sizes, "tokens": mi.tokens_template + mi.tokens_search,
-                   "cfg4_literal": bool(B == 1 and G == 1),     # BASELINE.json configs[3]: one stream per GPU
+                   # BASELINE.json configs[3] taken literally: 8 independent streams, ONE per GPU, on 8 GPUs;
+                   # cfg4_shape: the per-GPU shape of that configuration (one tracker on the GPU) at any N
+                   "cfg4_literal": bool(B == 1 and G == 1 and world == 8), "cfg4_shape": bool(B == 1 and G == 1),
+                   "cpu_affinity": affinity,
                    "ingest": ingest_text, "launch": "eager" if args.eager else "hipGraph",
                    "weights": "synthetic seeded encoder + fitted head (no reference weights exist)"},
         "per_stream_fps": fps / (world * B),
@@ -439,21 +454,37 @@ def run_rank(args):
         # HBM/fabric bytes per launch of the dominant kernel: PMC passes cannot run inside this process
         # (rocprofv3 --pmc is a separate run, one counter group per pass), so the number comes from the
         # committed summary of those passes on the same kernel and shape, with its provenance
+        # ... and ONLY while the kernel that is running is the kernel that was counted: the summary records the
+        # build identity of the dominant kernel's translation unit (vt_build_info(): sha256 over its sources and
+        # compile flags, stamped into the library by build.py); any other build gets traffic = null
         traffic, traffic_src = None, None
-        for pmc_name in ("r05_dominant_kernel_pmc.json", "r04_dominant_kernel_pmc.json", "r03_dominant_kernel_pmc.json"):
-            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-            if traffic is None and os.path.exists(pmc_path):
-                try:
-                    pm = json.load(open(pmc_path))
-                    if pm.get("kernel_family") == dom["name"] and pm.get("streams_per_pass") == Bg:
+        build_id = vt.build_info()
+        pmc_path = os.path.join(ROOT, "profiles", "r06_dominant_kernel_pmc.json")
+        if os.path.exists(pmc_path):
+            try:
+                pm = json.load(open(pmc_path))
+                if pm.get("kernel_family") == dom["name"] and pm.get("streams_per_pass") == Bg:
+                    if pm.get("kernel_source_sha256") and pm.get("kernel_source_sha256") == build_id.get("k_gemm256"):
                         traffic = pm["traffic_bytes_per_launch"]
                         traffic_src = pm["provenance"]
-                except Exception:
-                    pass
+                    else:
+                        traffic_src = (f"null: profiles/r06_dominant_kernel_pmc.json was collected on kernel build "
+                                       f"{str(pm.get('kernel_source_sha256'))[:12]}, this library is {str(build_id.get('k_gemm256'))[:12]}")
+            except Exception:
+                pass
+        # the same kernel inside the timed region: it shares the chip with the other engine's kernels there, so
+        # its flops of a step over its share (eager pass) of the measured step time
+        in_run = None
+        if dom["flops"] > 0 and tot > 0:
+            in_run = G * dom["flops"] / ((dt / K) * (dom["ms"] / tot)) / 1e12 / PEAK_BF16_TFLOPS
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src, "kernel_build": build_id.get("k_gemm256"),
+            "in_run_frac": in_run,
+            "in_run_source": "the dominant kernel's flops of one timed step (all engines) / (measured ms_per_step x the kernel's "
+                             "share of the eager instrumented pass) / peak: what the kernel delivers while it shares the chip "
+                             "with the other engine's kernels - `frac` is the kernel alone on the chip",
             "source": "HIP events bound to every dispatch (hipExtLaunchKernelGGL start / stop events) of ONE engine's "
                       "eager instrumented pass (vt_group_profile_device, 5 passes) on the library's own stream, right "
                       "after the timed region - not the timed hipGraph replays. They read 3-4 us per launch ABOVE "
@@ -622,11 +653,37 @@ def run_rank(args):
     # ---- byte-bound kernels against the HBM roofline (north_star: "HBM GB/s against gfx950 peak") ------
     if not args.no_profile and rank == 0:
         bk = []
-        for (cw, ch) in ((1920, 1080), (3840, 2160)):
-            us = vt.op_nv12_to_rgb8_bench(cw, ch, iters=50)
-            by = cw * ch * 4.5                                  # 1.5 B read + 3 B written per pixel
-            bk.append({"kernel": "nv12_to_rgb8_kernel", "frame": f"{cw}x{ch}", "us": us,
-                       "algorithmic_bytes": by, "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS})
+
+        def time_converter(cw, ch, nfr, iters):
+            """the reference's whole-frame converter through the product ABI, device-resident random frames, torch events
+            on the stream the calls are enqueued on; nfr == 0: vt_nv12_to_rgb8_device, else nfr frames per launch"""
+            n_ = max(nfr, 1)
+            src = torch.randint(0, 256, (n_, cw * ch * 3 // 2), dtype=torch.uint8, device=dev)
+            dst = torch.empty((n_, cw * ch * 3), dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream(dev)
+            ins, outs, lens = [src[i].data_ptr() for i in range(n_)], [dst[i].data_ptr() for i in range(n_)], [src.shape[1]] * n_
+
+            def once():
+                if nfr == 0:
+                    vt._check(vt.lib().vt_nv12_to_rgb8_device(local, ins[0], lens[0], cw, ch, outs[0], st.cuda_stream))
+                else:
+                    vt.nv12_to_rgb8_batch_device(ins, lens, cw, ch, outs, device=local, hip_stream=st.cuda_stream)
+            for _ in range(3):
+                once()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(iters):
+                once()
+            e1.record(st)
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        for (cw, ch, nfr) in ((1920, 1080, 0), (3840, 2160, 0), (1920, 1080, 30), (1920, 1080, 60)):
+            us = time_converter(cw, ch, nfr, 50 if nfr == 0 else 20)
+            by = cw * ch * 4.5 * max(nfr, 1)                    # 1.5 B read + 3 B written per pixel
+            bk.append({"kernel": "nv12_to_rgb8_kernel" if nfr == 0 else "nv12_to_rgb8_batch_kernel",
+                       "frame": f"{cw}x{ch}" + (f" x {nfr} frames in one launch (vt_nv12_to_rgb8_batch_device)" if nfr else ""),
+                       "us": us, "algorithmic_bytes": by, "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS})
         pre = [p for p in prof if p["name"] == "preproc_search"]
         if pre:
             crop_side = 4.0 * sq
@@ -685,7 +742,7 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def dry_run(args, vt, vd, world, rank, cfg_name, wl_text):
+def dry_run(args, vt, vd, world, rank, cfg_name, wl_text, affinity):
     """No GPU: the ranks rendezvous over gloo, broadcast the (tiny) weight blob, plan their streams and
     aggregate synthetic per-rank timings. Covers what the N > 1 leg adds around the kernels - the
     launcher, the collective record, the per-rank plan and the aggregation - on a CPU-only machine."""
@@ -699,7 +756,9 @@ def dry_run(args, vt, vd, world, rank, cfg_name, wl_text):
         collective["world_size"] = dist.get_world_size()
         del blob
     B = args.streams if args.streams > 0 else 2
+    G = 1 if args.streams == 1 else args.groups
     plan = vd.plan_rank(rank, world, B, args.ring)
+    masks = vd.gather_objects({"rank": rank, "running_on": sorted(os.sched_getaffinity(0)), **affinity})
     local_dt = 0.5 + 0.25 * rank                    # synthetic: rank r "took" 0.5 + r/4 seconds
     agg = vd.aggregate_throughput(B * args.steps, local_dt)
     per_rank = vd.gather_per_rank(B * args.steps / local_dt)
@@ -709,7 +768,10 @@ def dry_run(args, vt, vd, world, rank, cfg_name, wl_text):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": agg["seconds"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "none (dry run: synthetic timings, no kernels ran)",
-            "config": {"workload": wl_text, "vit_config": cfg_name, "streams_per_gpu": B},
+            "config": {"workload": wl_text, "vit_config": cfg_name, "streams_per_gpu": B, "engines_per_gpu": G,
+                       "cfg4_literal": bool(B == 1 and G == 1 and world == 8), "cfg4_shape": bool(B == 1 and G == 1),
+                       "cpu_affinity": affinity},
+            "cpu_affinity_by_rank": masks,
             "per_rank_fps": per_rank, "collective": collective,
             "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             "global_stream_ids_rank0": plan["global_stream_ids"]}))

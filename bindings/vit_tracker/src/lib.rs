@@ -9,7 +9,11 @@
 //!   BBox::new / BBox::from_array   src/selection_state.rs:44, src/tracker_context.rs:94
 //!
 //! Nothing unwinds across the C boundary (the host is built with panic = "abort", Cargo.toml:37):
-//! every C entry returns a status code, surfaced here as `Err(TrackError)`.
+//! every C entry returns a status code, surfaced here as `Err(TrackError)`. For the same reason this
+//! file contains no `assert!`, `unwrap()`, `expect(` or `panic!` and no slice indexing that can fail
+//! (tests/test_rust_binding.py greps for them): a view the library cannot take is an `Err` from
+//! `update`; `init`, whose result the host discards (src/tracker_context.rs:88), records the error and
+//! the next `update` returns it.
 pub mod sys;
 
 use ndarray::ArrayView3;
@@ -62,6 +66,8 @@ impl From<sys::VtResult> for TrackResult {
 
 pub struct VitTrack {
     h: *mut sys::vt_tracker,
+    /// an `init` that failed (the host ignores init's result): returned by the next `update`
+    pending: Option<TrackError>,
 }
 // Constructed on the main thread (src/main.rs:49 -> src/pipeline_ir.rs:89), used only on the GStreamer
 // streaming thread behind a Mutex (src/pipeline.rs:55-67,110-119). The C handle has no thread affinity
@@ -87,28 +93,46 @@ impl VitTrack {
         if rc != sys::VT_OK {
             Err(last(rc))
         } else {
-            Ok(Self { h })
+            Ok(Self { h, pending: None })
         }
     }
 
-    fn rgb_view(img: &ArrayView3<u8>) -> (*const u8, c_int, c_int, c_int) {
+    /// The (H, W, 3) RGB8 views the host builds (src/nv12_convert.rs:90, src/pipeline_ir.rs:142) have strides
+    /// (W*3, 3, 1); rows may be padded. Anything else is VT_ERR_INVALID_ARG - never a panic (panic = "abort").
+    fn rgb_view(img: &ArrayView3<u8>) -> Result<(*const u8, c_int, c_int, c_int), TrackError> {
         let (h, w, c) = img.dim();
-        let s = img.strides(); // (W*3, 3, 1) for the views the host builds (src/nv12_convert.rs:90, src/pipeline_ir.rs:142)
-        assert!(c == 3 && s[2] == 1 && s[1] == 3, "RGB8 HWC view expected");
-        (img.as_ptr(), w as c_int, h as c_int, s[0] as c_int)
+        let bad = |text: &str| TrackError { code: sys::VT_ERR_INVALID_ARG, text: text.into() };
+        let (s0, s1, s2) = match img.strides() {
+            [a, b, c] => (*a, *b, *c),
+            _ => return Err(bad("3-dimensional view expected")),
+        };
+        if c != 3 || s2 != 1 || s1 != 3 || s0 < 3 * w as isize {
+            return Err(bad("RGB8 HWC view with strides (>= W*3, 3, 1) expected"));
+        }
+        if w > c_int::MAX as usize || h > c_int::MAX as usize || s0 > c_int::MAX as isize {
+            return Err(bad("view too large"));
+        }
+        Ok((img.as_ptr(), w as c_int, h as c_int, s0 as c_int))
     }
 
-    /// ≙ src/tracker_context.rs:88 (the host discards the result; `()` keeps its code unchanged)
+    /// ≙ src/tracker_context.rs:88 (the host discards the result; `()` keeps its code unchanged). A failure is kept
+    /// and returned by the next `update` (which the host calls on the same frame, :90).
     pub fn init(&mut self, img: &ArrayView3<u8>, bbox: BBox) {
-        let (p, w, h, s) = Self::rgb_view(img);
-        unsafe {
-            sys::vt_init_rgb8(self.h, p, w, h, s, bbox);
-        }
+        self.pending = match Self::rgb_view(img) {
+            Err(e) => Some(e),
+            Ok((p, w, h, s)) => {
+                let rc = unsafe { sys::vt_init_rgb8(self.h, p, w, h, s, bbox) };
+                if rc != sys::VT_OK { Some(last(rc)) } else { None }
+            }
+        };
     }
 
     /// ≙ src/tracker_context.rs:90,120
     pub fn update(&mut self, img: &ArrayView3<u8>) -> Result<TrackResult, TrackError> {
-        let (p, w, h, s) = Self::rgb_view(img);
+        if let Some(e) = self.pending.take() {
+            return Err(e);
+        }
+        let (p, w, h, s) = Self::rgb_view(img)?;
         let mut r = sys::VtResult::default();
         let rc = unsafe { sys::vt_update_rgb8(self.h, p, w, h, s, &mut r) };
         if rc != sys::VT_OK {
@@ -117,27 +141,36 @@ impl VitTrack {
         Ok(r.into())
     }
 
+    /// (Y plane, UV plane) of a packed NV12 buffer, or VT_ERR_SHORT_BUFFER / VT_ERR_INVALID_ARG - no indexing that can panic
+    fn nv12_planes(nv12: &[u8], w: usize, h: usize) -> Result<(*const u8, *const u8, c_int, c_int), TrackError> {
+        let px = w.checked_mul(h).filter(|_| w <= c_int::MAX as usize && h <= c_int::MAX as usize);
+        let px = px.ok_or(TrackError { code: sys::VT_ERR_INVALID_ARG, text: "frame size out of range".into() })?;
+        let uv = nv12.get(px..).filter(|uv| uv.len() >= px / 2);
+        let uv = uv.ok_or(TrackError { code: sys::VT_ERR_SHORT_BUFFER, text: "nv12 buffer shorter than w*h*3/2".into() })?;
+        Ok((nv12.as_ptr(), uv.as_ptr(), w as c_int, h as c_int))
+    }
+
     /// Fused NV12 ingest (not in the original crate): the same result as init/update on the RGB frame
     /// nv12_full_to_rgb_parallel (src/nv12_convert.rs:46) would have produced, without converting the
     /// whole frame; lets src/pipeline.rs:104-106 go. `nv12` is the mapped buffer (Y plane then
     /// interleaved UV, stride == width as src/nv12_convert.rs:53-54 assumes).
     pub fn init_nv12(&mut self, nv12: &[u8], w: usize, h: usize, bbox: BBox) {
-        if nv12.len() < w * h * 3 / 2 {
-            return;
-        }
-        unsafe {
-            sys::vt_init_nv12(self.h, nv12.as_ptr(), nv12[w * h..].as_ptr(), w as c_int, h as c_int, w as c_int, w as c_int, bbox);
-        }
+        self.pending = match Self::nv12_planes(nv12, w, h) {
+            Err(e) => Some(e),
+            Ok((y, uv, wi, hi)) => {
+                let rc = unsafe { sys::vt_init_nv12(self.h, y, uv, wi, hi, wi, wi, bbox) };
+                if rc != sys::VT_OK { Some(last(rc)) } else { None }
+            }
+        };
     }
 
     pub fn update_nv12(&mut self, nv12: &[u8], w: usize, h: usize) -> Result<TrackResult, TrackError> {
-        if nv12.len() < w * h * 3 / 2 {
-            return Err(TrackError { code: sys::VT_ERR_SHORT_BUFFER, text: "nv12 buffer shorter than w*h*3/2".into() });
+        if let Some(e) = self.pending.take() {
+            return Err(e);
         }
+        let (y, uv, wi, hi) = Self::nv12_planes(nv12, w, h)?;
         let mut r = sys::VtResult::default();
-        let rc = unsafe {
-            sys::vt_update_nv12(self.h, nv12.as_ptr(), nv12[w * h..].as_ptr(), w as c_int, h as c_int, w as c_int, w as c_int, &mut r)
-        };
+        let rc = unsafe { sys::vt_update_nv12(self.h, y, uv, wi, hi, wi, wi, &mut r) };
         if rc != sys::VT_OK {
             return Err(last(rc));
         }
@@ -146,8 +179,14 @@ impl VitTrack {
 
     /// Fused YUY2 ingest: the capture format of the live IR pipeline (src/pipeline_ir.rs:27-41)
     pub fn update_yuy2(&mut self, yuy2: &[u8], w: usize, h: usize) -> Result<TrackResult, TrackError> {
-        if yuy2.len() < w * h * 2 {
-            return Err(TrackError { code: sys::VT_ERR_SHORT_BUFFER, text: "yuy2 buffer shorter than w*h*2".into() });
+        if let Some(e) = self.pending.take() {
+            return Err(e);
+        }
+        let need = w.checked_mul(h).and_then(|p| p.checked_mul(2)).filter(|_| w <= (c_int::MAX / 2) as usize && h <= c_int::MAX as usize);
+        match need {
+            None => return Err(TrackError { code: sys::VT_ERR_INVALID_ARG, text: "frame size out of range".into() }),
+            Some(n) if yuy2.len() < n => return Err(TrackError { code: sys::VT_ERR_SHORT_BUFFER, text: "yuy2 buffer shorter than w*h*2".into() }),
+            Some(_) => {}
         }
         let mut r = sys::VtResult::default();
         let rc = unsafe { sys::vt_update_yuy2(self.h, yuy2.as_ptr(), w as c_int, h as c_int, (2 * w) as c_int, &mut r) };
@@ -176,7 +215,9 @@ impl Drop for VitTrack {
 /// ≙ nv12_full_to_rgb_parallel (src/nv12_convert.rs:46-92) on the GPU, bit for bit (including the
 /// all-zero frame for a short buffer, :48-50); for callers that still want the whole RGB frame.
 pub fn nv12_full_to_rgb(nv12: &[u8], w: usize, h: usize, device: i32) -> Result<Vec<u8>, TrackError> {
-    let mut out = vec![0u8; w * h * 3];
+    let bytes = w.checked_mul(h).and_then(|p| p.checked_mul(3)).filter(|_| w <= c_int::MAX as usize && h <= c_int::MAX as usize);
+    let bytes = bytes.ok_or(TrackError { code: sys::VT_ERR_INVALID_ARG, text: "frame size out of range".into() })?;
+    let mut out = vec![0u8; bytes];
     let rc = unsafe { sys::vt_nv12_to_rgb8(device, nv12.as_ptr(), nv12.len(), w as c_int, h as c_int, out.as_mut_ptr()) };
     if rc != sys::VT_OK {
         return Err(last(rc));

@@ -1,11 +1,11 @@
-//! Raw declarations of include/vittrack_hip.h (VT_ABI_VERSION 4), one for one and in header order.
+//! Raw declarations of include/vittrack_hip.h (VT_ABI_VERSION 5), one for one and in header order.
 //! tests/test_rust_binding.py parses this file and the header and fails on any drift: a missing or
 //! extra function, a different argument count / order / type, a struct whose fields or size differ.
 #![allow(non_camel_case_types, dead_code)]
 
 use std::ffi::{c_char, c_int, c_void};
 
-pub const VT_ABI_VERSION: c_int = 4;
+pub const VT_ABI_VERSION: c_int = 5;
 pub const VT_MAX_STREAMS: c_int = 1024;
 pub const VT_RCCL_ID_BYTES: usize = 128;
 
@@ -141,6 +141,7 @@ extern "C" {
     pub fn vt_config_default(cfg: *mut VtConfig);
     pub fn vt_last_error() -> *const c_char;
     pub fn vt_abi_version() -> c_int;
+    pub fn vt_build_info() -> *const c_char;
     pub fn vt_device_count() -> c_int;
     pub fn vt_recommended_streams(info: *const VtModelInfo, max_streams: c_int) -> c_int;
     pub fn vt_plan_engines(info: *const VtModelInfo, n_streams: c_int, sizes: *mut c_int, cap: c_int) -> c_int;
@@ -181,6 +182,7 @@ extern "C" {
     pub fn vt_group_enqueue_host(g: *mut vt_group, host_frames: *const VtFrame, n: c_int) -> c_int;
     pub fn vt_group_wait_next(g: *mut vt_group, out: *mut VtResult, n: c_int) -> c_int;
     pub fn vt_group_host_redos(g: *const vt_group) -> c_int;
+    pub fn vt_group_graph_captures(g: *const vt_group) -> c_int;
 
     pub fn vt_import_dmabuf(device_id: c_int, fd: c_int, bytes: usize, out: *mut *mut vt_extmem, d_ptr: *mut *mut c_void) -> c_int;
     pub fn vt_release_dmabuf(m: *mut vt_extmem);
@@ -190,6 +192,7 @@ extern "C" {
     pub fn vt_host_unregister(device_id: c_int, host_ptr: *mut c_void) -> c_int;
 
     pub fn vt_nv12_to_rgb8(device_id: c_int, nv12: *const u8, len: usize, w: c_int, h: c_int, rgb_out: *mut u8) -> c_int;
+    pub fn vt_nv12_to_rgb8_batch_device(device_id: c_int, d_nv12: *const *const c_void, lens: *const usize, n: c_int, w: c_int, h: c_int, d_rgb_out: *const *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn vt_nv12_to_rgb8_device(device_id: c_int, d_nv12: *const c_void, len: usize, w: c_int, h: c_int, d_rgb_out: *mut c_void, hip_stream: *mut c_void) -> c_int;
 
     pub fn vt_overlay_nv12_device(device_id: c_int, d_y: *mut c_void, width: c_int, height: c_int, stride: c_int, cmds: *const VtDrawCmd, n: c_int, hip_stream: *mut c_void) -> c_int;
@@ -204,14 +207,4 @@ extern "C" {
     pub fn vt_group_set_state_box(g: *mut vt_group, stream: c_int, box4: *const f32) -> c_int;
     pub fn vt_group_read_tensor(g: *mut vt_group, stream: c_int, name: *const c_char, out: *mut f32, capacity: i64) -> i64;
 
-    pub fn vt_op_gemm_bf16(device_id: c_int, a: *const u16, w: *const u16, bias: *const f32, c_inout: *mut f32, m: c_int, n: c_int, k: c_int, epilogue: c_int, cfg: c_int, rowstat_in: *const f32, colsum: *const f32, rowstat_out: *mut f32, eps: f32) -> c_int;
-    pub fn vt_op_gemm_bench(device_id: c_int, m: c_int, n: c_int, k: c_int, epilogue: c_int, cfg: c_int, iters: c_int, us_out: *mut f32) -> c_int;
-    pub fn vt_op_conv3x3_relu_bf16(device_id: c_int, t: *const u16, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, c: c_int, n: c_int, cfg: c_int) -> c_int;
-    pub fn vt_op_headconv_bf16(device_id: c_int, t: *const u16, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, cin: c_int, n: c_int, conv3x3: c_int, r: c_int, ncb: c_int, iters: c_int, us_out: *mut f32) -> c_int;
-    pub fn vt_op_headconv_ln_bf16(device_id: c_int, xh: *const u16, xl: *const u16, gamma: *const f32, beta: *const f32, eps: f32, ntok: c_int, off: c_int, w: *const u16, bias: *const f32, out: *mut f32, b: c_int, grid: c_int, d: c_int, n: c_int, fused: c_int, r: c_int, ncb: c_int, iters: c_int, us_out: *mut f32) -> c_int;
-    pub fn vt_op_qkv_bf16(device_id: c_int, a: *const u16, w: *const u16, bias: *const f32, qk_out: *mut f32, vt_out: *mut f32, b: c_int, tokens: c_int, d: c_int, cfg: c_int, vt_perm: c_int, rowstat_in: *const f32, colsum: *const f32) -> c_int;
-    pub fn vt_op_attention_bf16(device_id: c_int, q: *const u16, k: *const u16, v: *const u16, out: *mut f32, b: c_int, n: c_int, h: c_int, mode: c_int) -> c_int;
-    pub fn vt_op_attention_bench(device_id: c_int, b: c_int, n: c_int, h: c_int, mode: c_int, iters: c_int, us_out: *mut f32) -> c_int;
-    pub fn vt_op_nv12_to_rgb8_bench(device_id: c_int, w: c_int, h: c_int, iters: c_int, us_out: *mut f32) -> c_int;
-    pub fn vt_op_layernorm(device_id: c_int, x: *const f32, gamma: *const f32, beta: *const f32, y: *mut f32, m: c_int, d: c_int) -> c_int;
 }

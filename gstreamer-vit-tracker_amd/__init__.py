@@ -20,6 +20,10 @@ from . import synth    # noqa: F401
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITTRACK_HIP_LIB", os.path.join(PKG_DIR, "libvittrack_hip.so"))
+# operator-level entry points (include/vittrack_hip_ops.h): a library of their own, for tests and tuning tools; a tuning
+# build named by VITTRACK_HIP_LIB carries them too
+OPS_LIB_PATH = os.environ.get("VITTRACK_HIP_OPS_LIB") or os.environ.get("VITTRACK_HIP_LIB") or \
+    os.path.join(PKG_DIR, "libvittrack_hip_ops.so")
 
 PIX_RGB8, PIX_NV12, PIX_YUY2 = 0, 1, 2
 
@@ -78,20 +82,24 @@ _lib = None
 
 # every symbol include/vittrack_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "vt_config_default", "vt_last_error", "vt_abi_version", "vt_device_count", "vt_create",
+    "vt_config_default", "vt_last_error", "vt_abi_version", "vt_build_info", "vt_device_count", "vt_create",
     "vt_create_from_device_blob", "vt_destroy", "vt_get_model_info", "vt_init_rgb8",
     "vt_update_rgb8", "vt_init_yuy2", "vt_update_yuy2", "vt_init_nv12", "vt_update_nv12", "vt_init_rgb8_device",
     "vt_update_rgb8_device", "vt_init_nv12_device", "vt_update_nv12_device", "vt_group_create",
     "vt_group_create_from_device_blob", "vt_group_destroy", "vt_group_streams",
     "vt_group_get_model_info", "vt_group_init_device", "vt_group_enqueue_device", "vt_group_wait",
     "vt_recommended_streams", "vt_plan_engines", "vt_import_dmabuf", "vt_release_dmabuf", "vt_export_dmabuf", "vt_host_register", "vt_host_unregister", "vt_group_update_device", "vt_group_hip_stream", "vt_group_init_host", "vt_group_update_host", "vt_group_enqueue_host", "vt_group_wait_next",
-    "vt_group_host_redos", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
+    "vt_group_host_redos", "vt_group_graph_captures", "vt_nv12_to_rgb8", "vt_nv12_to_rgb8_device", "vt_nv12_to_rgb8_batch_device", "vt_overlay_nv12", "vt_overlay_nv12_device", "vt_overlay_rgb8",
     "vt_overlay_rgb8_device",
     "vt_group_profile_device", "vt_group_enable_taps", "vt_group_set_tuning", "vt_group_set_state_box", "vt_tracker_as_group",
-    "vt_group_read_tensor", "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
-    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_conv3x3_relu_bf16", "vt_op_headconv_bf16",
-    "vt_op_headconv_ln_bf16",
+    "vt_group_read_tensor",
     "vt_rccl_unique_id", "vt_broadcast_weights_rccl", "vt_free_device_blob",
+]
+# every symbol include/vittrack_hip_ops.h declares (libvittrack_hip_ops.so; the product library exports none of them)
+OPS_EXPORTS = [
+    "vt_op_gemm_bf16", "vt_op_gemm_bench", "vt_op_qkv_bf16", "vt_op_attention_bf16",
+    "vt_op_attention_bench", "vt_op_layernorm", "vt_op_nv12_to_rgb8_bench", "vt_op_nv12_to_rgb8_batch_bench", "vt_op_conv3x3_relu_bf16", "vt_op_headconv_bf16",
+    "vt_op_headconv_ln_bf16",
 ]
 
 
@@ -112,6 +120,7 @@ def lib():
         pass
     L = ctypes.CDLL(LIB_PATH)
     L.vt_last_error.restype = c_char_p
+    L.vt_build_info.restype = c_char_p
     L.vt_config_default.argtypes = [POINTER(CConfig)]
     L.vt_create.argtypes = [c_char_p, c_int, POINTER(CConfig), POINTER(c_void_p)]
     L.vt_create_from_device_blob.argtypes = [c_void_p, c_size_t, c_int, POINTER(CConfig),
@@ -156,6 +165,7 @@ def lib():
     L.vt_group_enqueue_host.argtypes = [c_void_p, POINTER(CFrame), c_int]
     L.vt_group_wait_next.argtypes = [c_void_p, POINTER(CResult), c_int]
     L.vt_group_host_redos.argtypes = [c_void_p]
+    L.vt_group_graph_captures.argtypes = [c_void_p]
     L.vt_group_hip_stream.argtypes = [c_void_p]
     L.vt_group_hip_stream.restype = c_void_p
     L.vt_group_profile_device.argtypes = [c_void_p, POINTER(CFrame), c_int, c_int,
@@ -170,20 +180,13 @@ def lib():
     L.vt_nv12_to_rgb8.argtypes = [c_int, u8p, c_size_t, c_int, c_int, u8p]
     L.vt_nv12_to_rgb8_device.argtypes = [c_int, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                          c_void_p]
+    L.vt_nv12_to_rgb8_batch_device.argtypes = [c_int, POINTER(c_void_p), POINTER(c_size_t), c_int, c_int, c_int,
+                                               POINTER(c_void_p), c_void_p]
     L.vt_overlay_nv12_device.argtypes = [c_int, c_void_p, c_int, c_int, c_int, POINTER(CDrawCmd), c_int,
                                          c_void_p]
     L.vt_overlay_nv12.argtypes = [c_int, u8p, c_int, c_int, POINTER(CDrawCmd), c_int]
     L.vt_overlay_rgb8_device.argtypes = L.vt_overlay_nv12_device.argtypes
     L.vt_overlay_rgb8.argtypes = L.vt_overlay_nv12.argtypes
-    u16p, fp = POINTER(c_uint16), POINTER(c_float)
-    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_float]
-    L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
-    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp]
-    L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
-    L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
-    L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
-    L.vt_op_conv3x3_relu_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int]
-    L.vt_op_nv12_to_rgb8_bench.argtypes = [c_int, c_int, c_int, c_int, fp]
     L.vt_rccl_unique_id.argtypes = [u8p]
     L.vt_broadcast_weights_rccl.argtypes = [u8p, c_int, c_int, c_int, c_char_p, POINTER(c_void_p),
                                             POINTER(c_size_t)]
@@ -193,10 +196,50 @@ def lib():
     return L
 
 
+_ops = None
+
+
+def ops_lib():
+    """Load libvittrack_hip_ops.so: the product's objects + the operator-level entry points (tests, tuning tools)."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    if not os.path.exists(OPS_LIB_PATH):
+        raise VtError(-2, f"{OPS_LIB_PATH} not built: run `python __graft_entry__.py`")
+    lib()       # torch / HIP runtime first, as above
+    L = ctypes.CDLL(OPS_LIB_PATH)
+    L.vt_last_error.restype = c_char_p
+    u16p, fp = POINTER(c_uint16), POINTER(c_float)
+    L.vt_op_gemm_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp, fp, c_float]
+    L.vt_op_gemm_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, fp]
+    L.vt_op_qkv_bf16.argtypes = [c_int, u16p, u16p, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, fp, fp]
+    L.vt_op_attention_bf16.argtypes = [c_int, u16p, u16p, u16p, fp, c_int, c_int, c_int, c_int]
+    L.vt_op_attention_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, fp]
+    L.vt_op_layernorm.argtypes = [c_int, fp, fp, fp, fp, c_int, c_int]
+    L.vt_op_conv3x3_relu_bf16.argtypes = [c_int, u16p, u16p, fp, fp, c_int, c_int, c_int, c_int, c_int]
+    L.vt_op_nv12_to_rgb8_bench.argtypes = [c_int, c_int, c_int, c_int, fp]
+    L.vt_op_nv12_to_rgb8_batch_bench.argtypes = [c_int, c_int, c_int, c_int, c_int, fp]
+    _ops = L
+    return L
+
+
 def _check(rc):
     if rc < 0:
         raise VtError(rc, lib().vt_last_error().decode(errors="replace"))
     return rc
+
+
+def _check_op(rc):
+    if rc < 0:
+        raise VtError(rc, ops_lib().vt_last_error().decode(errors="replace"))
+    return rc
+
+
+def build_info() -> dict:
+    """vt_build_info(): 'key=value;...' of the loaded library - ABI version and the sha256 build.py stamped into the
+    translation unit of the dominant kernels (their sources + compile flags)"""
+    txt = lib().vt_build_info().decode()
+    return dict(kv.split("=", 1) for kv in txt.split(";") if "=" in kv)
 
 
 def recommended_streams(info: "CModelInfo", max_streams: int = 128) -> int:
@@ -600,6 +643,10 @@ class Group:
             self._keep["done"] = done + 1
         return [TrackResult(r) for r in out]
 
+    def graph_captures(self) -> int:
+        """hipGraph captures since creation: all crop tiers are captured when the engine is created, none inside a pass"""
+        return lib().vt_group_graph_captures(self._h)
+
     def host_redos(self) -> int:
         return lib().vt_group_host_redos(self._h)
 
@@ -649,6 +696,15 @@ def nv12_full_to_rgb(nv12_data: np.ndarray, width: int, height: int, device: int
 
 # ---- overlays (the reference's per-frame drawing, on the GPU) -------------------------------------
 
+def nv12_to_rgb8_batch_device(d_nv12_ptrs, lens, w: int, h: int, d_rgb_ptrs, device: int = 0, hip_stream=None):
+    """vt_nv12_to_rgb8_batch_device: n device-resident packed NV12 frames -> n RGB8 frames in one launch per 64 frames"""
+    n = len(d_nv12_ptrs)
+    ins = (c_void_p * n)(*[int(p) for p in d_nv12_ptrs])
+    outs = (c_void_p * n)(*[int(p) for p in d_rgb_ptrs])
+    ls = (c_size_t * n)(*[int(x) for x in lens])
+    _check(lib().vt_nv12_to_rgb8_batch_device(device, ins, ls, n, w, h, outs, hip_stream))
+
+
 def draw_cmd(kind, x=0, y=0, w=0, h=0, p=0, value=0, text="") -> CDrawCmd:
     return CDrawCmd(kind, x, y, w, h, p, value, text.encode()[:35])
 
@@ -687,7 +743,7 @@ def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1
     rs = None if rowstat is None else np.ascontiguousarray(rowstat, np.float32)
     cs = None if colsum is None else np.ascontiguousarray(colsum, np.float32)
     ro = np.zeros((M, 2), np.float32) if want_rowstat else None
-    _check(lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
+    _check_op(ops_lib().vt_op_gemm_bf16(device, _u16(a_bits), _u16(w_bits),
                                  _f32(b) if b is not None else None, _f32(c), M, N, K, epilogue, cfg,
                                  _f32(rs) if rs is not None else None, _f32(cs) if cs is not None else None,
                                  _f32(ro) if ro is not None else None, eps))
@@ -696,7 +752,7 @@ def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1
 
 def op_gemm_bench(M, N, K, epilogue, cfg=-1, iters=50, device=0) -> float:
     us = c_float()
-    _check(lib().vt_op_gemm_bench(device, M, N, K, epilogue, cfg, iters, byref(us)))
+    _check_op(ops_lib().vt_op_gemm_bench(device, M, N, K, epilogue, cfg, iters, byref(us)))
     return float(us.value)
 
 
@@ -710,7 +766,7 @@ def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0, cfg=-1, vt_perm=0,
     vt = np.empty((B * (D // 64), 64, npad), np.float32)
     rs = None if rowstat is None else np.ascontiguousarray(rowstat, np.float32)
     cs = None if colsum is None else np.ascontiguousarray(colsum, np.float32)
-    _check(lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),
+    _check_op(ops_lib().vt_op_qkv_bf16(device, _u16(a_bits), _u16(w_bits), _f32(bias), _f32(qk),
                                 _f32(vt), B, tokens, D, cfg, vt_perm,
                                 _f32(rs) if rs is not None else None, _f32(cs) if cs is not None else None))
     return qk, vt
@@ -719,21 +775,28 @@ def op_qkv_bf16(a_bits, w_bits, bias, B, tokens, D, device=0, cfg=-1, vt_perm=0,
 def op_attention_bf16(q_bits, k_bits, v_bits, B, N, H, device=0, mode=-1):
     q_bits, k_bits, v_bits = (np.ascontiguousarray(x, np.uint16) for x in (q_bits, k_bits, v_bits))
     out = np.empty((B * N, H * 64), np.float32)
-    _check(lib().vt_op_attention_bf16(device, _u16(q_bits), _u16(k_bits), _u16(v_bits), _f32(out),
+    _check_op(ops_lib().vt_op_attention_bf16(device, _u16(q_bits), _u16(k_bits), _u16(v_bits), _f32(out),
                                       B, N, H, mode))
     return out
 
 
 def op_attention_bench(B, N, H, mode=-1, iters=30, device=0) -> float:
     us = c_float()
-    _check(lib().vt_op_attention_bench(device, B, N, H, mode, iters, byref(us)))
+    _check_op(ops_lib().vt_op_attention_bench(device, B, N, H, mode, iters, byref(us)))
     return float(us.value)
 
 
 def op_nv12_to_rgb8_bench(w, h, iters=50, device=0) -> float:
     """mean microseconds per launch of the whole-frame NV12 -> RGB8 converter (device-resident)"""
     us = c_float()
-    _check(lib().vt_op_nv12_to_rgb8_bench(device, w, h, iters, byref(us)))
+    _check_op(ops_lib().vt_op_nv12_to_rgb8_bench(device, w, h, iters, byref(us)))
+    return float(us.value)
+
+
+def op_nv12_to_rgb8_batch_bench(w, h, n, iters=20, device=0) -> float:
+    """mean microseconds per launch of the n-frames-per-launch converter on device-resident random frames"""
+    us = c_float(0.0)
+    _check_op(ops_lib().vt_op_nv12_to_rgb8_batch_bench(device, w, h, n, iters, byref(us)))
     return float(us.value)
 
 
@@ -744,7 +807,7 @@ def op_conv3x3_relu(t_bf16_bits, w_bf16_bits, bias, B, grid, cfg=-1, device=0):
     w = np.ascontiguousarray(w_bf16_bits, np.uint16)
     C, N = t.shape[1], w.shape[0]
     out = np.empty((t.shape[0], N), np.float32)
-    _check(lib().vt_op_conv3x3_relu_bf16(device, t.ctypes.data_as(POINTER(ctypes.c_uint16)),
+    _check_op(ops_lib().vt_op_conv3x3_relu_bf16(device, t.ctypes.data_as(POINTER(ctypes.c_uint16)),
                                          w.ctypes.data_as(POINTER(ctypes.c_uint16)),
                                          _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, C, N, cfg))
     return out
@@ -757,7 +820,7 @@ def op_headconv(t_bf16_bits, w_bf16_bits, bias, B, grid, conv3x3=True, R=0, ncb=
     Cin, N = t.shape[1], w.shape[0]
     out = np.empty((t.shape[0], N), np.float32)
     u16 = POINTER(ctypes.c_uint16)
-    _check(lib().vt_op_headconv_bf16(device, t.ctypes.data_as(u16), w.ctypes.data_as(u16),
+    _check_op(ops_lib().vt_op_headconv_bf16(device, t.ctypes.data_as(u16), w.ctypes.data_as(u16),
                                      _f32(np.ascontiguousarray(bias, np.float32)), _f32(out), B, grid, Cin, N,
                                      1 if conv3x3 else 0, R, ncb, 0, None))
     return out
@@ -774,7 +837,7 @@ def op_headconv_ln(xh_bits, xl_bits, gamma, beta, w_bf16_bits, bias, B, grid, nt
     assert xh.shape == xl.shape == (B * ntok, D) and w.shape[1] == D
     out = np.empty((B * grid * grid, N), np.float32)
     u16 = POINTER(ctypes.c_uint16)
-    _check(lib().vt_op_headconv_ln_bf16(device, xh.ctypes.data_as(u16), xl.ctypes.data_as(u16),
+    _check_op(ops_lib().vt_op_headconv_ln_bf16(device, xh.ctypes.data_as(u16), xl.ctypes.data_as(u16),
                                         _f32(np.ascontiguousarray(gamma, np.float32)),
                                         _f32(np.ascontiguousarray(beta, np.float32)), c_float(eps), ntok, off,
                                         w.ctypes.data_as(u16), _f32(np.ascontiguousarray(bias, np.float32)), _f32(out),
@@ -785,7 +848,7 @@ def op_headconv_ln(xh_bits, xl_bits, gamma, beta, w_bf16_bits, bias, B, grid, nt
 def op_headconv_ln_bench(B, grid, D, N, ntok, off, fused=True, R=0, ncb=0, iters=50, device=0) -> float:
     """mean microseconds of the head's first layer with the final LayerNorm (fused: one launch, else two)"""
     us = c_float()
-    _check(lib().vt_op_headconv_ln_bf16(device, None, None, None, None, c_float(1e-6), ntok, off, None, None, None, B, grid,
+    _check_op(ops_lib().vt_op_headconv_ln_bf16(device, None, None, None, None, c_float(1e-6), ntok, off, None, None, None, B, grid,
                                         D, N, 1 if fused else 0, R, ncb, iters, byref(us)))
     return float(us.value)
 
@@ -793,7 +856,7 @@ def op_headconv_ln_bench(B, grid, D, N, ntok, off, fused=True, R=0, ncb=0, iters
 def op_headconv_bench(B, grid, Cin, N, conv3x3=True, R=0, ncb=0, iters=50, device=0) -> float:
     """mean microseconds per launch of the band kernel on pseudo-random operands"""
     us = c_float()
-    _check(lib().vt_op_headconv_bf16(device, None, None, None, None, B, grid, Cin, N, 1 if conv3x3 else 0, R, ncb,
+    _check_op(ops_lib().vt_op_headconv_bf16(device, None, None, None, None, B, grid, Cin, N, 1 if conv3x3 else 0, R, ncb,
                                      iters, byref(us)))
     return float(us.value)
 
@@ -803,6 +866,6 @@ def op_layernorm(x, gamma, beta, device=0):
     g = np.ascontiguousarray(gamma, np.float32)
     b = np.ascontiguousarray(beta, np.float32)
     y = np.empty_like(x)
-    _check(lib().vt_op_layernorm(device, _f32(x), _f32(g), _f32(b), _f32(y), x.shape[0],
+    _check_op(ops_lib().vt_op_layernorm(device, _f32(x), _f32(g), _f32(b), _f32(y), x.shape[0],
                                  x.shape[1]))
     return y

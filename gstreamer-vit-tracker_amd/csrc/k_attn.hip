@@ -419,25 +419,12 @@ __device__ __forceinline__ float sum_p8(const bf16x8_t& p, float acc) {
     return acc;
 }
 
-// The same sum on the matrix pipe: v_mfma_f32_4x4x4_16b_bf16 with A = ones adds, for every lane, the lane's own four B
-// values to its accumulator (D[i][j] = sum_k 1 * B[k][j] + C[i][j], column j of block lane / 4 = the lane itself; all four
-// result registers are equal) - 2 x 8 cycles of matrix pipe per 8 probabilities instead of 4 v_dot2c (~10 cycles of vector
-// issue each) in a loop that is bound by vector issue.
-__device__ __forceinline__ f32x4_t sum_p8_mfma(const bf16x8_t& p, f32x4_t acc) {
-    const bf16x4_t one4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
-    const bf16x4_t lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
-    acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, lo, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, hi, acc, 0, 0, 0);
-}
-
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     return __builtin_fmaxf(__builtin_fmaxf(a, b), c);   // selected as v_max3_f32
 }
 
-// NS: ring stages of 16 KiB (3: two tiles ahead, 48 KiB -> 3 workgroups per CU; 2: one tile ahead,
-// 32 KiB -> 4 workgroups per CU if the kernel also fits 128 registers); WPS: waves per SIMD the
-// register allocation must allow.
-// One pass of a workgroup over its (stream, head, 128 queries). CAREFUL = false (ORD 0 only): the FIRST
+// AT3_NS = 3 ring stages of 16 KiB: two tiles ahead, 48 KiB -> 3 workgroups per CU.
+// One pass of a workgroup over its (stream, head, 128 queries). CAREFUL = false: the FIRST
 // pass takes p = 2^score as it is, with no running maximum at all - per step 16 v_max3, a cross-half
 // swap, a ballot and a branch less, and the exponentials start the moment the scores leave the matrix
 // pipe. Afterwards every query's row sum must lie in [2^-60, 2^60] (it does whenever the scores stayed
@@ -447,11 +434,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // +-32 window the two passes are the same arithmetic. Two inlined copies, one after the other, rather
 // than a loop with a flag: with a back edge hipcc keeps the whole set-up live (190 VGPRs, 98 spilled
 // SGPRs: two waves per SIMD instead of three).
-// SUMV (ORD 0): the row sums are kept on the vector ALU (sum_p8: 16 v_dot2c per 64-key step and lane, the
+// The row sums are kept on the vector ALU (sum_p8: 16 v_dot2c per 64-key step and lane, the
 // two lane halves added once at the end) instead of a third P.V MFMA against a tile of ones - 4 of the 20
 // MFMAs of a step; without the running-maximum bookkeeping the step is bound by the matrix pipe, not by
 // vector issue (profiles/r03_attention_ab.txt).
-template <int ORD, int NS, bool CAREFUL, int SUMV>
+template <bool CAREFUL>
 __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                          bf16_t* __restrict__ out, int tokens, int H, int npad, int tid, int block) {
     const int lane = tid & 63;
@@ -472,7 +459,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     const int h = bh % H, b = bh / H;
     const int qb = xb * 4 + wave;
 
-    f32x16_t o0, o1, osum;
+    f32x16_t o0, o1;
     constexpr bool careful = CAREFUL;
     const int q = qb * 32 + l31;
     const int qc = q < tokens ? q : tokens - 1;     // idle rows repeat the last query, never stored
@@ -513,21 +500,19 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     const uint32_t fa2 = (uint32_t)(l31 * 128 + (((4 + half) ^ sw) << 4));
     const uint32_t fa3 = (uint32_t)(l31 * 128 + (((6 + half) ^ sw) << 4));
 
-    // O^T accumulators; osum = ones · P^T: every register of it ends up holding the row sum of the
-    // lane's query (summed over both lane halves by the MFMA itself); only register 0 is used.
+    // O^T accumulators.
     // Softmax reference: p = 2^(score - m_run). m_run stays 0 - no subtraction pass at all - while
     // every query's scores stay inside [-ATT_WIN, +ATT_WIN] log2 units (p <= 2^32 is harmless in
     // bf16 / f32 and the normalisation at the end divides it out); it moves, with a rescale of what
     // has been accumulated, only when a maximum leaves that window (upwards in any step; downwards
     // in the first step, so that a row of uniformly tiny scores does not underflow).
     float m_run = 0.0f;
-    float lsum = 0.0f;                   // SUMV 1: this lane's share of its query's row sum
-    f32x4_t lacc = {0.0f, 0.0f, 0.0f, 0.0f};   // SUMV 2: the same, accumulated by 4x4x4 MFMAs (register 0)
+    float lsum = 0.0f;                   // this lane's share of its query's row sum (the two lane halves are added at the end)
     bool shifted = false;                // wave-uniform: some lane's m_run != 0
-    const bf16x8_t ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    constexpr int NS = AT3_NS;
     constexpr int AHEAD = NS - 1;        // tiles in flight beyond the one being computed
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; osum[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; }
     AT3_STAGE_TILE(0, 0)
     if (AHEAD > 1 && nt > 1) AT3_STAGE_TILE(1, AT3_STAGE)
     int sbase = 0;                       // LDS offset of the stage holding tile kt
@@ -557,82 +542,6 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         const char* p0 = st + fa0; const char* p1 = st + fa1;
         const char* p2 = st + fa2; const char* p3 = st + fa3;
 #define AT3_RD(P, OFF) (*reinterpret_cast<const bf16x8_t*>((P) + (OFF)))
-        constexpr bool SPLIT = ORD == 1;
-        if constexpr (ORD == 2) {
-            // Sequential halves, every fragment loaded right before its use (scheduling regions fenced):
-            //   K(a) -> QK(a) -> softmax(a) -> V(a) -> P.V(a) -> K(b) -> QK(b) -> softmax(b) -> V(b) -> P.V(b)
-            // Peak live registers: O / row-sum accumulators 48 + Q 16 + scores 16 + P 8 + one set of 16
-            // fragment registers: the kernel fits 128 registers, i.e. FOUR workgroups per CU (with the
-            // 2-stage ring's 32 KiB). Nothing overlaps inside a wave; the other three waves of the SIMD do.
-            const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
-                                   0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#define AT3_SEQ_HALF(KBYTES, KOFF, FIRST_HALF, PA_, PB_)                                           \
-    {                                                                                              \
-        f32x16_t S;                                                                                \
-        {                                                                                          \
-            const bf16x8_t k0 = AT3_RD(p0, KBYTES), k1 = AT3_RD(p1, KBYTES);                       \
-            const bf16x8_t k2 = AT3_RD(p2, KBYTES), k3 = AT3_RD(p3, KBYTES);                       \
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], zero, 0, 0, 0);                 \
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], S, 0, 0, 0);                    \
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], S, 0, 0, 0);                    \
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], S, 0, 0, 0);                    \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (kt == nt - 1 && (tokens & 63) != 0) {                                                  \
-            const int key0 = kt * 64 + (KOFF) + 4 * half;                                          \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
-                if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
-        }                                                                                          \
-        if constexpr (careful) {                                                                   \
-        if (shifted) {                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
-        }                                                                                          \
-        float mx = max3f(S[0], S[1], S[2]);                                                        \
-        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mx = max3f(mx, S[r], S[r + 1]);          \
-        mx = xhalf_max(fmaxf(mx, S[15]));                                                          \
-        const bool first = (FIRST_HALF) && kt == 0;                                                \
-        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {                          \
-            const float dm = first ? mx : fmaxf(mx, 0.0f);                                         \
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);                        \
-            m_run += dm;                                                                           \
-            shifted = true;                                                                        \
-            osum[0] *= alpha; lsum *= alpha; lacc[0] *= alpha;                                     \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-                o0[r] *= alpha; o1[r] *= alpha;                                                    \
-                S[r] -= dm;                                                                        \
-            }                                                                                      \
-        }                                                                                          \
-        }                                                                                          \
-        bf16x8_t pa, pb;                                                                           \
-        {                                                                                          \
-            union { uint32_t u[4]; bf16x8_t v; } c0, c1;                                           \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[2 * e]), __builtin_amdgcn_exp2f(S[2 * e + 1])); \
-                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[8 + 2 * e]), __builtin_amdgcn_exp2f(S[8 + 2 * e + 1])); \
-            }                                                                                      \
-            pa = c0.v; pb = c1.v;                                                                  \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        {                                                                                          \
-            const bf16x8_t va0 = AT3_RD(PA_, 8192), vb0 = AT3_RD(PA_, 12288);                      \
-            const bf16x8_t va1 = AT3_RD(PB_, 8192), vb1 = AT3_RD(PB_, 12288);                      \
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pa, o0, 0, 0, 0);                    \
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pa, o1, 0, 0, 0);                    \
-            if constexpr (SUMV == 1) lsum = sum_p8(pa, lsum);                                      \
-            else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pa, lacc);                            \
-            else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);          \
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pb, o0, 0, 0, 0);                    \
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pb, o1, 0, 0, 0);                    \
-            if constexpr (SUMV == 1) lsum = sum_p8(pb, lsum);                                      \
-            else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pb, lacc);                            \
-            else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);          \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    }
-            AT3_SEQ_HALF(0, 0, true, p0, p1)
-            AT3_SEQ_HALF(4096, 32, false, p2, p3)
-#undef AT3_SEQ_HALF
-        } else {
         bf16x8_t kf0[4], kf1[4], vf0[4], vf1[4];
         kf0[0] = AT3_RD(p0, 0); kf0[1] = AT3_RD(p1, 0); kf0[2] = AT3_RD(p2, 0); kf0[3] = AT3_RD(p3, 0);
         kf1[0] = AT3_RD(p0, 4096); kf1[1] = AT3_RD(p1, 4096); kf1[2] = AT3_RD(p2, 4096); kf1[3] = AT3_RD(p3, 4096);
@@ -643,83 +552,13 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         const f32x16_t zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                                0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         f32x16_t s0, s1;
-        if constexpr (SPLIT) {              // chain a completes first: its softmax starts under chain b
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
-        } else {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
-            }
+        for (int ks = 1; ks < 4; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], s1, 0, 0, 0);
         }
-        if constexpr (SPLIT) {
-            // One softmax per 32 keys, in the order QK(a) QK(b) | softmax(a) | P.V(a) | softmax(b) |
-            // P.V(b): the QK MFMAs of the second half are in the matrix pipe while the VALU works on
-            // the first half's scores, and the first half's P.V MFMAs while it works on the second
-            // half's - MFMA and VALU time of ONE wave overlap instead of relying on the other two
-            // waves of the SIMD being in a different phase (they are not: all workgroups start
-            // together and run the same code). Each half takes its own window decision AFTER the
-            // previous half's P.V MFMAs were issued (they complete before a rescale touches O), the
-            // textbook order at 32-key granularity.
-#define AT3_HALF(S, KOFF, FIRST_HALF, G0)                                                          \
-    {                                                                                              \
-        if (kt == nt - 1 && (tokens & 63) != 0) {                                                  \
-            const int key0 = kt * 64 + (KOFF) + 4 * half;                                          \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
-                if (key0 + (r & 3) + 8 * (r >> 2) >= tokens) S[r] = -INFINITY;                     \
-        }                                                                                          \
-        if constexpr (careful) {                                                                   \
-        if (shifted) {                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) S[r] -= m_run;                          \
-        }                                                                                          \
-        float mx = max3f(S[0], S[1], S[2]);                                                        \
-        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mx = max3f(mx, S[r], S[r + 1]);          \
-        mx = xhalf_max(fmaxf(mx, S[15]));                                                          \
-        const bool first = (FIRST_HALF) && kt == 0;                                                \
-        if (!__all(mx <= ATT_WIN) || (first && !__all(mx >= -ATT_WIN))) {                          \
-            const float dm = first ? mx : fmaxf(mx, 0.0f);                                         \
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);                        \
-            m_run += dm;                                                                           \
-            shifted = true;                                                                        \
-            osum[0] *= alpha;                                                                      \
-            lsum *= alpha; lacc[0] *= alpha;                                                       \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-                o0[r] *= alpha; o1[r] *= alpha;                                                    \
-                S[r] -= dm;                                                                        \
-            }                                                                                      \
-        }                                                                                          \
-        }                                                                                          \
-        bf16x8_t pa, pb;                                                                           \
-        {                                                                                          \
-            union { uint32_t u[4]; bf16x8_t v; } c0, c1;                                           \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-                c0.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[2 * e]), __builtin_amdgcn_exp2f(S[2 * e + 1])); \
-                c1.u[e] = pack_bf16x2(__builtin_amdgcn_exp2f(S[8 + 2 * e]), __builtin_amdgcn_exp2f(S[8 + 2 * e + 1])); \
-            }                                                                                      \
-            pa = c0.v; pb = c1.v;                                                                  \
-        }                                                                                          \
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0], pa, o0, 0, 0, 0);                    \
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0], pa, o1, 0, 0, 0);                    \
-        if constexpr (SUMV == 1) lsum = sum_p8(pa, lsum);                                          \
-        else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pa, lacc);                                \
-        else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, osum, 0, 0, 0);              \
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[G0 + 1], pb, o0, 0, 0, 0);                \
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[G0 + 1], pb, o1, 0, 0, 0);                \
-        if constexpr (SUMV == 1) lsum = sum_p8(pb, lsum);                                          \
-        else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pb, lacc);                                \
-        else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, osum, 0, 0, 0);              \
-    }
-            AT3_HALF(s0, 0, true, 0)
-            AT3_HALF(s1, 32, false, 2)
-#undef AT3_HALF
-        } else {
         if (kt == nt - 1 && (tokens & 63) != 0) {      // block-uniform: keys >= tokens -> -inf
                 const int key0 = kt * 64 + 4 * half;
     #pragma unroll
@@ -749,8 +588,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dm);   // O and the sum are 0 in step 0
                 m_run += dm;
                 shifted = true;
-                osum[0] *= alpha;
-                lsum *= alpha; lacc[0] *= alpha;
+                lsum *= alpha;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o0[r] *= alpha; o1[r] *= alpha;
@@ -774,12 +612,8 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
             for (int g = 0; g < 4; ++g) {       // 16-key groups of the step
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[g], pf[g], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[g], pf[g], o1, 0, 0, 0);
-                if constexpr (SUMV == 1) lsum = sum_p8(pf[g], lsum);
-                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(pf[g], lacc);
-                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g], osum, 0, 0, 0);
+                lsum = sum_p8(pf[g], lsum);
             }
-        }
-        }   // ORD != 2
         sbase = sbase + AT3_STAGE >= NS * AT3_STAGE ? 0 : sbase + AT3_STAGE;
     }
     if constexpr (!CAREFUL) {
@@ -809,14 +643,10 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
                 }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 8192), c0.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p0, 12288), c0.v, o1, 0, 0, 0);
-                if constexpr (SUMV == 1) lsum = sum_p8(c0.v, lsum);
-                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(c0.v, lacc);
-                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c0.v, osum, 0, 0, 0);
+                lsum = sum_p8(c0.v, lsum);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 8192), c1.v, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT3_RD(p1, 12288), c1.v, o1, 0, 0, 0);
-                if constexpr (SUMV == 1) lsum = sum_p8(c1.v, lsum);
-                else if constexpr (SUMV == 2) lacc = sum_p8_mfma(c1.v, lacc);
-                else osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, c1.v, osum, 0, 0, 0);
+                lsum = sum_p8(c1.v, lsum);
             }
         }
     }
@@ -824,7 +654,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     if constexpr (!careful) {
         // did every query of the workgroup stay in range? (the barriers of a pass are workgroup-wide, so
         // the four waves repeat together or not at all; the flags live in the dead ring)
-        const float l = SUMV == 1 ? xhalf_sum(lsum) : (SUMV == 2 ? xhalf_sum(lacc[0]) : osum[0]);
+        const float l = xhalf_sum(lsum);
         const bool bad = active && !(l >= 0x1p-60f && l <= 0x1p60f);
         const unsigned long long bm = __ballot(bad);
         int* flag = reinterpret_cast<int*>(smem);
@@ -834,7 +664,7 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
         __syncthreads();                  // flags read before anything overwrites them
         if (any) return true;
     }
-    const float l_run = SUMV == 1 ? xhalf_sum(lsum) : (SUMV == 2 ? xhalf_sum(lacc[0]) : osum[0]);
+    const float l_run = xhalf_sum(lsum);
 
     // ---- epilogue: O^T (d on registers, query on lanes) -> LDS [32 q][128 B] per wave -> rows ----
     {
@@ -864,45 +694,32 @@ __device__ __forceinline__ bool at3_pass(char* smem, const bf16_t* __restrict__ 
     return false;
 }
 
-template <int ORD, int NS, int WPS, int SUMV = 0>
-__global__ __launch_bounds__(256, WPS) void attention_dma_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(256, 3) void attention_dma_kernel(const bf16_t* __restrict__ qk,
                                                             const bf16_t* __restrict__ vt,
                                                             bf16_t* __restrict__ out, int tokens,
-                                                            int H, int npad, int stagger) {
-    __shared__ __attribute__((aligned(16))) char smem[NS * AT3_STAGE];
-    // Three workgroups share a CU (one wave of each per SIMD). Dispatched together and running the
-    // same code they sit in the same phase of the step at the same time, so their MFMA, softmax-VALU
-    // and memory parts add up on the SIMD instead of overlapping (profiles/README.md). `stagger`
-    // delays the workgroups of the first residency wave by 0, 1/3 and 2/3 of a step.
-    if (stagger) {
-        const int k = (int)(blockIdx.x / 256u) % 3;
-        for (int i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-    if constexpr (ORD == 0 || ORD == 1 || (ORD == 2 && SUMV > 0)) {
-        if (at3_pass<ORD, NS, false, SUMV>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
-            __syncthreads();
-            // the (rare) second pass rebuilds every address from opaque copies of its inputs: if the
-            // compiler could see that the two inlined passes compute the same values it would keep the
-            // first pass's alive for the second (189 VGPRs instead of 156: a wave per SIMD less)
-            int t2 = threadIdx.x, b2 = blockIdx.x, tk = tokens, hh = H, np2 = npad;
-            const bf16_t* q2 = qk; const bf16_t* v2 = vt; bf16_t* o2 = out;
-            asm volatile("" : "+v"(t2));
-            asm volatile("" : "+s"(b2), "+s"(tk), "+s"(hh), "+s"(np2), "+s"(q2), "+s"(v2), "+s"(o2));
-            at3_pass<ORD, NS, true, SUMV>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
-        }
-    } else {
-        at3_pass<ORD, NS, true, 0>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x);
+                                                            int H, int npad) {
+    __shared__ __attribute__((aligned(16))) char smem[AT3_NS * AT3_STAGE];
+    // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc then spills
+    // (100 B of scratch) sits in the rare second pass only (checked in the ISA)
+    if (at3_pass<false>(smem, qk, vt, out, tokens, H, npad, (int)threadIdx.x, (int)blockIdx.x)) {
+        __syncthreads();
+        // the (rare) second pass rebuilds every address from opaque copies of its inputs: if the
+        // compiler could see that the two inlined passes compute the same values it would keep the
+        // first pass's alive for the second (189 VGPRs instead of 156: a wave per SIMD less)
+        int t2 = threadIdx.x, b2 = blockIdx.x, tk = tokens, hh = H, np2 = npad;
+        const bf16_t* q2 = qk; const bf16_t* v2 = vt; bf16_t* o2 = out;
+        asm volatile("" : "+v"(t2));
+        asm volatile("" : "+s"(b2), "+s"(tk), "+s"(hh), "+s"(np2), "+s"(q2), "+s"(v2), "+s"(o2));
+        at3_pass<true>(smem, q2, v2, o2, tk, hh, np2, t2, b2);
     }
 }
 
-// mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged,
-// 3 = LDS-DMA ring with permuted Vt (default when tokens % 4 == 0 and npad % 64 == 0), -1 = choose.
-// 4, 5 = measured alternatives of mode 3 kept for A/B (operator-level entry points only): 4 = one
-// softmax per 32 keys with QK(b) under softmax(a) (74 vs 70 us at 30 streams), 5 = 2-stage ring and
-// sequential halves in 119 registers = four workgroups per CU (76.8 vs 72.8 us: a fourth wave per
-// SIMD does not help - MFMA and VALU time of this instruction mix add up on a SIMD whatever the
-// number of waves; a 2-stage ring alone is as fast as the 3-stage one, 72.3 us); 6 = mode 3's careful
-// pass alone (the default until round 3).
+// mode: 0 = key-split (few streams), 1 = independent waves, 2 = LDS-shared tiles, register staged (the fallbacks for
+// token counts the DMA kernel does not take), 3 = LDS-DMA ring with permuted Vt (default when tokens % 4 == 0 and
+// npad % 64 == 0), -1 = choose. The alternatives of mode 3 that rounds 2-5 measured and dropped (one softmax per 32
+// keys; sequential halves in <= 128 registers = four workgroups per CU; row sums by a ones-MFMA or by 4x4x4 MFMAs;
+// the careful pass alone) are in git history with their numbers in profiles/r03_attention_ab.txt and
+// profiles/r05_attention_modes.txt.
 int attention_pick_mode(int tokens, int npad) {
     if (npad % 64 != 0) return 0;
     return (tokens % 4 == 0) ? 3 : 2;   // tokens % 4: the QKV epilogue's 4-token runs stay inside a stream
@@ -927,32 +744,7 @@ hipError_t launch_attention_mode(const bf16_t* qk, const bf16_t* vt, bf16_t* out
         vt_launch(attention_lds_kernel, dim3((nqb + 3) / 4, H, B), dim3(256), 0, st, qk, vt,
                            out, tokens, H, npad);
     } else if (mode == 3) {
-        // launch bound of 3 waves per SIMD: the first pass fits 168 registers without a spill; what hipcc
-        // then spills (100 B of scratch) sits in the rare second pass only (checked in the ISA)
-        vt_launch((attention_dma_kernel<0, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 7) {               // tuning only: mode 3 with the row sums from a P.V MFMA against ones
-        vt_launch((attention_dma_kernel<0, 3, 3, 0>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 6) {               // tuning only: mode 3 without the unchecked first pass (round 2's kernel)
-        vt_launch((attention_dma_kernel<3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 4) {               // tuning only: one softmax per 32 keys (measured slower)
-        vt_launch((attention_dma_kernel<1, 3, 3, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 8) {               // tuning: mode 3 with the row sums by 4x4x4 MFMAs (A = ones)
-        vt_launch((attention_dma_kernel<0, 3, 3, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 9) {               // tuning: FOUR workgroups per CU (<= 128 registers, 2-stage ring, sequential halves)
-        // with the unchecked first pass and 4x4x4-MFMA row sums: the one structure round 4 left untried
-        vt_launch((attention_dma_kernel<2, 2, 4, 2>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 10) {              // the same with v_dot2c row sums
-        vt_launch((attention_dma_kernel<2, 2, 4, 1>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
-    } else if (mode == 5) {               // 4 workgroups per CU: 2-stage ring, sequential halves in <= 128 registers
-        vt_launch((attention_dma_kernel<2, 2, 4>), dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt,
-                           out, tokens, H, npad, 0);
+        vt_launch(attention_dma_kernel, dim3(((nqb + 3) / 4) * H * B), dim3(256), 0, st, qk, vt, out, tokens, H, npad);
     } else {
         return hipErrorInvalidValue;
     }

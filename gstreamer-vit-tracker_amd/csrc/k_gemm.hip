@@ -727,7 +727,7 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
 //   4: 64x64   2x2 ring 3 k128   one stream: proj, fc2 (half the iterations of the dependent K loop)
 //   5: 64x64   2x2 ring 2 k128   one stream: QKV; two or three streams: proj
 //   6: 128x128 2x2 ring 2 k128   (measured, never the best: kept for the sweeps)
-// 17 is the 256x256 8-wave kernel of k_gemm256.hip. Numbers 4-16 were experiments on this kernel
+// 18 / 19 are the 256x256 8-wave kernels of k_gemm256.hip (17: round 1's schedule, removed). Numbers 4-16 were experiments on this kernel
 // (256-wide tiles with the same loop, 8-wave blocks, deeper rings, K-tile depth 32, register
 // staging) that never beat 128x128 ring 2 and were removed after the sweep kept in
 // profiles/gemm_sweep_r01.txt.
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
     X(6, 128, 128, 2, 2, 2, 128, EPI, false) \
     X(7, 64, 64, 2, 2, 3, 128, EPI, true)    \
     X(8, 128, 64, 2, 2, 3, 128, EPI, true)
-#define GEMM_NUM_CFG 20   // valid: 0..8 (this file) and 17, 18, 19 (k_gemm256.hip)
+#define GEMM_NUM_CFG 20   // valid: 0..8 (this file) and 18, 19 (k_gemm256.hip)
 
 template <int BM, int BN, int WVM, int WVN, int NS, int BK, int EPI, bool LW>
 static hipError_t prepare_cfg() {
@@ -850,7 +850,6 @@ int gemm_pick_config(int M, int N, int K, int epilogue, bool conv) {
 const char* gemm_config_name(int cfg) {
     static const char* n[] = {"64x64x4", "128x128x3", "64x64x2", "128x128x2", "64x64x3k128", "64x64x2k128", "128x128x2k128",
                               "64x64x3k128lw", "128x64x3k128lw"};
-    if (cfg == GEMM_CFG_256P8) return "256x256p8";
     if (cfg == GEMM_CFG_256P4) return "256x256p4";
     if (cfg == GEMM_CFG_256PP) return "256x256pp";
     return (cfg >= 0 && cfg <= GEMM_CFG_SMALL_MAX) ? n[cfg] : "?";
@@ -879,9 +878,8 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
         return hipErrorInvalidValue;
     if (!x_epi && (!a.bias || ((a.rowstat || a.cstat_in) && !a.colsum))) return hipErrorInvalidValue;
     if (a.cstat_in && (cfg > GEMM_CFG_SMALL_MAX || a.rowstat || (a.K % (4 * VT_STAT_CHUNK)) != 0 || a.K > 1024)) return hipErrorInvalidValue;
-    if (cfg == GEMM_CFG_256P8) return launch_gemm256(a, epilogue, 1, st);
-    if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, 2, st);
-    if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, 3, st);
+    if (cfg == GEMM_CFG_256P4) return launch_gemm256(a, epilogue, false, st);
+    if (cfg == GEMM_CFG_256PP) return launch_gemm256(a, epilogue, true, st);
     switch (epilogue) {
         case EPI_F32_POS: return launch_epi<EPI_F32_POS>(a, cfg, st);
         case EPI_RESID: return launch_epi<EPI_RESID>(a, cfg, st);
@@ -895,14 +893,14 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
 
 int gemm_effective_config(const GemmArgs& a, int epilogue) {
     const int cfg = gemm_pick_config(a.M, a.N, a.K, epilogue, a.conv_grid > 0);
-    if (cfg >= GEMM_CFG_256P8 && !gemm256_fits(a, epilogue))       // e.g. an operand beyond 4 GiB
+    if (cfg >= GEMM_CFG_256_MIN && !gemm256_fits(a, epilogue))       // e.g. an operand beyond 4 GiB
         return (a.N % 128 == 0 && a.M >= 2048) ? 3 : 2;
     return cfg;
 }
 
 bool gemm_finalizes_rowstat(const GemmArgs& a, int epilogue) {
     const bool x_epi = epilogue == EPI_F32_POS || epilogue == EPI_RESID || epilogue == EPI_F32;
-    return x_epi && a.rowstat_out && a.panel_cnt && a.cstat && a.N <= 1536 && gemm_effective_config(a, epilogue) >= GEMM_CFG_256P8;
+    return x_epi && a.rowstat_out && a.panel_cnt && a.cstat && a.N <= 1536 && gemm_effective_config(a, epilogue) >= GEMM_CFG_256_MIN;
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st) {

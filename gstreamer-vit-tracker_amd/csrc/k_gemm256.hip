@@ -1,4 +1,4 @@
-// k_gemm256.hip — 256x256-tile, 8-wave, phase-interleaved bf16 MFMA GEMM for gfx950 (config 17).
+// k_gemm256.hip — 256x256-tile, 8-wave, phase-interleaved bf16 MFMA GEMM for gfx950 (configs 18, 19).
 //
 //   C[M,N] = A[M,K] · W[N,K]^T (+ the fused epilogues of k_gemm.hip), one 256x256 output tile per
 //   workgroup, one workgroup per CU (128 KiB of LDS, 512 threads).
@@ -10,38 +10,22 @@
 //
 // Geometry
 //   * 8 waves as 2 (M) x 4 (N); a wave owns a 128 x 64 piece of C = 8 x 4 v_mfma_f32_16x16x32_bf16
-//     accumulators (128 VGPRs). It is computed as four 64 x 32 quadrants (i, j), one per PHASE,
-//     16 MFMAs each, in the order (0,0) (0,1) (1,1) (1,0).
+//     accumulators (128 VGPRs). It is computed as two 64 x 64 halves (rows i = 0, 1), one per PHASE,
+//     32 MFMAs each.
 //   * K-tile depth 64. One K-tile in LDS = four HALF-tiles of 16 KiB, each 128 rows x 128 B:
 //       A_i = the rows every wave uses for quadrant row i  (rows wr*128 + i*64 + 0..63, wr = 0,1)
 //       B_j = the W rows every wave uses for quadrant column j (wc*64 + j*32 + 0..31, wc = 0..3)
-//     so that a half-tile is dead as soon as its phase has read it: A0 and B0 after phase 1 (B0
-//     and B1 stay in registers), B1 after phase 2, A1 after phase 3. Two K-tile buffers (128 KiB).
+//     so that a half-tile is dead as soon as its phase has read it (B0 and B1 stay in registers over
+//     both phases). Two K-tile buffers (128 KiB).
 //   * LDS image as in k_gemm.hip: 128-B rows, 16-B chunk c of row r stored at c ^ ((r >> 1) & 7);
 //     LDS-DMA (global_load_lds_dwordx4) writes lane-linear, so the XOR sits on the per-lane SOURCE
 //     address and again on the ds_read_b128 (conflict-free for 16-row fragments too: the 16 lanes
 //     of each read group land on 16 distinct 16-B slots of the 256-B bank row).
 //
-// Schedule (per K-tile t, buffer t & 1; one half-tile = 2 LDS-DMA instructions per thread)
-//     phase 1: read B0, A0(t)   stage B1(t+1)   wait vmcnt(8)  | barrier | MFMA (0,0) | barrier
-//     phase 2: read B1(t)       stage A1(t+1)   wait vmcnt(8)  | barrier | MFMA (0,1) | barrier
-//     phase 3: read A1(t)       stage A0(t+2)                  | barrier | MFMA (1,1) | barrier
-//     phase 4: —                stage B0(t+2)   wait vmcnt(8)  | barrier | MFMA (1,0) | barrier
+// Schedule: two phases of 32 MFMAs per K-tile, documented at g256_mainloop2 below (RAW / WAR argument there).
 //   The two wave rows run one barrier apart (wr = 1 executes one extra s_barrier before the loop,
 //   wr = 0 one after it), so on every SIMD one wave is in its MFMA section while the other reads
 //   LDS and issues loads.
-//   Ordering rules this relies on (MI355X guide, "Read a staged buffer one phase AFTER the wait
-//   that retires it"):
-//     RAW  a half-tile is read in phase p only if every wave executed the counted vmcnt that
-//          retires it before the first barrier of a phase <= p-1: A0/B0(t+1) are retired in phase
-//          4 of tile t and read in phase 1 of t+1; B1(t+1) in phase 1 / read in 2; A1(t+1) in
-//          phase 2 / read in 3. vmcnt retires in issue order, and at each wait exactly four
-//          younger half-tiles (8 instructions) may stay in flight.
-//     WAR  a half-tile is overwritten no earlier than two phases after its last read (A0(t+2) in
-//          phase 3 is the tightest: A0(t) was last read in phase 1); every reader has waited
-//          lgkmcnt(0) for those reads before the MFMAs of the reading phase, i.e. before the
-//          second barrier of that phase, and the other wave row is at most one barrier behind.
-//   The last two K-tiles stage less and use the correspondingly smaller counts (TAIL 1, 2).
 //
 // Epilogues go through LDS (dead after the loop) so that global stores are whole rows:
 // f32 outputs in two passes of 128 rows x 1 KiB, bf16 outputs in one pass of 256 rows x 512 B.
@@ -65,17 +49,9 @@ __device__ __forceinline__ f32x4_t mma16(const bf16x8_t& xa, const bf16x8_t& wb,
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, c, 0, 0, 0);
 }
 
-// tuning builds only (VT_AB_ANT): the A operand's LDS-DMA with the non-temporal hint (aux = 2), so that a
-// streamed row panel does not push the W tiles an XCD keeps re-reading out of its L2
-#ifdef VT_AB_ANT
-__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
-}
-#define G256_GLDS_A glds16_nt
-#else
+// (the A operand's LDS-DMA with the non-temporal hint was measured in round 4 and lost: A then loses the in-step reuse
+// by the six workgroups of a panel - profiles/r04_fc1_tile_order_cache_policy.txt; git history has the variant)
 #define G256_GLDS_A glds16
-#endif
 #define G256_RD(ptr, off) (*reinterpret_cast<const bf16x8_t*>((ptr) + (off)))
 
 // LDS accesses of the persistent kernel's wave-private epilogue, as inline asm: hipcc (ROCm 7.2) puts
@@ -128,154 +104,11 @@ __device__ __forceinline__ void lds_wait2_asm(u32x4_t& a, u32x4_t& b) {
         glds16(s_ + ((J) ? boff10 : boff00), d_);                                                \
         glds16(s_ + ((J) ? boff11 : boff01), d_ + 8192);                                         \
     }
-// the compute half of a phase; the compiler places counted lgkmcnt waits in front of the MFMAs.
-// G256_T: diagnostic builds (-DVT_STAMPS) accumulate per-wave cycles of the load section, the two
-// barrier waits and the MFMA section; the product build carries no stamps.
-#ifdef VT_STAMPS
-#define G256_T(v) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#define G256_ACC() { st_load += st_b - st_a; st_bar += (st_c - st_b) + (st_e - st_d); st_mfma += st_d - st_c; st_a = st_e; }
-#else
-#define G256_T(v)
-#define G256_ACC()
-#endif
-#define G256_COMPUTE(I, J)                                                                       \
-    {                                                                                            \
-        G256_T(st_b)                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        __builtin_amdgcn_s_barrier();                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        G256_T(st_c)                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                           \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                         \
-            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                     \
-                _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                 \
-                    acc[I][mf][J][nf] = mma16<SWAP>(Af[mf][kk], Bf[J][nf][kk], acc[I][mf][J][nf]); \
-        __builtin_amdgcn_s_setprio(0);                                                           \
-        G256_T(st_d)                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        __builtin_amdgcn_s_barrier();                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        G256_T(st_e)                                                                             \
-        G256_ACC()                                                                               \
-    }
-
-template <bool SWAP>
-__device__ __forceinline__ void g256_mainloop(const GemmArgs& p, char* smem, int m0, int n0,
-                                              acc256_t& acc) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    // ---- staging addresses: piece (g, tid) of a half-tile = local row g*64 + (tid >> 3), stored
-    // chunk tid & 7, i.e. logical chunk (tid & 7) ^ ((row >> 1) & 7) -------------------------------
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-    auto a_off = [&](int i, int g) -> uint32_t {
-        int gm = m0 + g * 128 + i * 64 + srow;
-        gm = gm < p.M ? gm : p.M - 1;   // rows past M read the last row; never stored
-        return (uint32_t)(((size_t)gm * p.lda + schunk * 8) * 2);      // < 2^32: launch_gemm256
-    };
-    auto b_off = [&](int j, int g) -> uint32_t {
-        const int gn = n0 + (g * 2 + (srow >> 5)) * 64 + j * 32 + (srow & 31);
-        return (uint32_t)(((size_t)gn * p.ldw + schunk * 8) * 2);
-    };
-    const uint32_t aoff00 = a_off(0, 0), aoff01 = a_off(0, 1), aoff10 = a_off(1, 0), aoff11 = a_off(1, 1);
-    const uint32_t boff00 = b_off(0, 0), boff01 = b_off(0, 1), boff10 = b_off(1, 0), boff11 = b_off(1, 1);
-
-    // ---- fragment read addresses (16x16x32: lane -> row l & 15, k chunk (l >> 4) of the 32-deep half)
-    const int l15 = lane & 15, q = lane >> 4, sw = (lane >> 1) & 7;
-    const uint32_t a_k0 = (uint32_t)((wr * 64 + l15) * 128 + ((q ^ sw) << 4));
-    const uint32_t b_k0 = (uint32_t)(2 * G256_HALF + (wc * 32 + l15) * 128 + ((q ^ sw) << 4));
-    const char* pa0 = smem + a_k0;
-    const char* pa1 = smem + (a_k0 ^ 64);
-    const char* pb0 = smem + b_k0;
-    const char* pb1 = smem + (b_k0 ^ 64);
-
-    bf16x8_t Af[4][2], Bf[2][2][2];
-    const int nk = p.K >> 6;
-
-    // ---- prologue: all of tile 0 and the phase-3/4 half-tiles of tile 1 ---------------------------
-    G256_STAGE_A(0, 0, 0)
-    G256_STAGE_B(0, 0, 0)
-    G256_STAGE_B(1, 0, 0)
-    G256_STAGE_A(1, 0, 0)
-    G256_STAGE_A(0, 1, G256_BUF)
-    G256_STAGE_B(0, 1, G256_BUF)
-    wait_vmcnt<8>();                       // A0(0), B0(0) landed (this thread's pieces)
-    __builtin_amdgcn_s_barrier();          // ... and everybody else's
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // second wave row runs one barrier behind
-    __builtin_amdgcn_sched_barrier(0);
-
-#ifdef VT_STAMPS
-    unsigned long long st_a, st_b = 0, st_c = 0, st_d = 0, st_e = 0, st_load = 0, st_bar = 0, st_mfma = 0;
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
-    st_a = st_t0;
-#endif
-    int bo = 0;   // byte offset of the current tile's buffer
-    int kt = 0;
-    for (; kt < nk - 2; ++kt) {
-        const int bn = bo ^ G256_BUF;
-        G256_READ_B(0) G256_READ_A(0)
-        G256_STAGE_B(1, kt + 1, bn)
-        wait_vmcnt<8>();
-        G256_COMPUTE(0, 0)
-        G256_READ_B(1)
-        G256_STAGE_A(1, kt + 1, bn)
-        wait_vmcnt<8>();
-        G256_COMPUTE(0, 1)
-        G256_READ_A(1)
-        G256_STAGE_A(0, kt + 2, bo)
-        G256_COMPUTE(1, 1)
-        G256_STAGE_B(0, kt + 2, bo)
-        wait_vmcnt<8>();
-        G256_COMPUTE(1, 0)
-        bo = bn;
-        pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);
-        pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
-    }
-    {   // tile nk-2: nothing of tile nk exists
-        const int bn = bo ^ G256_BUF;
-        G256_READ_B(0) G256_READ_A(0)
-        G256_STAGE_B(1, kt + 1, bn)
-        wait_vmcnt<8>();
-        G256_COMPUTE(0, 0)
-        G256_READ_B(1)
-        G256_STAGE_A(1, kt + 1, bn)
-        wait_vmcnt<8>();
-        G256_COMPUTE(0, 1)
-        G256_READ_A(1)
-        G256_COMPUTE(1, 1)
-        wait_vmcnt<4>();                   // A0, B0 of the last tile; its B1, A1 may still fly
-        G256_COMPUTE(1, 0)
-        bo = bn;
-        pa0 = smem + (a_k0 ^ bo); pa1 = smem + ((a_k0 ^ 64) ^ bo);
-        pb0 = smem + (b_k0 ^ bo); pb1 = smem + ((b_k0 ^ 64) ^ bo);
-    }
-    {   // last tile
-        G256_READ_B(0) G256_READ_A(0)
-        wait_vmcnt<2>();                   // B1
-        G256_COMPUTE(0, 0)
-        G256_READ_B(1)
-        wait_vmcnt<0>();                   // A1
-        G256_COMPUTE(0, 1)
-        G256_READ_A(1)
-        G256_COMPUTE(1, 1)
-        G256_COMPUTE(1, 0)
-    }
-#ifdef VT_STAMPS
-    if (p.dbg && lane == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
-        d[0] = st_bar; d[1] = st_load; d[2] = st_mfma; d[3] = __builtin_amdgcn_s_memtime() - st_t0;
-    }
-#endif
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of wave row 1
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// ---- schedule v2: two LONG phases per K-tile (32 MFMAs each) -------------------------------------
-// In-kernel stamps of the 4-phase schedule above (profiles/README.md): each of its 8 barrier intervals
-// per K-tile lasts max(load section 232, MFMA section 289) + ~97 cycles of barrier latency for 256
-// cycles of matrix-pipe work (66 %). Halving the number of intervals halves that fixed cost:
+// ---- the schedule: two LONG phases per K-tile (32 MFMAs each) -----------------------------------------
+// Round 1's schedule had four phases of 16 MFMAs per K-tile (git history: config 17). In-kernel stamps of it
+// (profiles/README.md): each of its 8 barrier intervals per K-tile lasted max(load section 232, MFMA section 289)
+// + ~97 cycles of barrier latency for 256 cycles of matrix-pipe work (66 %). Halving the number of intervals
+// halves that fixed cost:
 //     P1(t): read B0, B1, A0(t)   stage A0, A1(t+1) -> other buffer   wait vmcnt(8): A1(t) landed
 //            lgkmcnt(0) | barrier | 32 MFMA: rows i = 0, both column halves | barrier
 //     P2(t): read A1(t)           stage B0, B1(t+2) -> this buffer    wait vmcnt(6): B(t+1), A0(t+1)
@@ -392,7 +225,7 @@ __device__ __forceinline__ void g256_mainloop2(const GemmArgs& p, char* smem, in
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI, int VER>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N >> 8;
@@ -435,8 +268,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const unsigned long long xs_t0 = __builtin_amdgcn_s_memtime(), xs_r0 = __builtin_amdgcn_s_memrealtime();
         (void)xs_r0;
 #endif
-        if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
-        else g256_mainloop<true>(p, smem, m0, n0, acc);
+        g256_mainloop2<true>(p, smem, m0, n0, acc);
 #ifdef VT_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long xs_t1 = __builtin_amdgcn_s_memtime();
@@ -474,13 +306,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const size_t ro = (size_t)mc * p.ldx * 2;
                 const uint32_t lo_ = (mc + 1 < p.M) ? lane_off : lane_off0;
                 a0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xh) + ro + lo_);
-#ifdef VT_AB_NOLO    /* tuning builds only: upper bound of what cutting the pair's bytes can buy (wrong results) */
-                a1 = u32x4_t{0u, 0u, 0u, 0u};
-#elif defined(VT_AB_LO8)
-                { const uint2 t2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.Xl) + ro + lo_); a1 = u32x4_t{t2.x, t2.y, 0u, 0u}; }
-#else
                 a1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xl) + ro + lo_);
-#endif
             } else if constexpr (EPI == EPI_F32_POS) {
                 const int m = out_row(i, it);
                 const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
@@ -544,13 +370,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const bool cst = p.cstat && (c8 & 7) == 0;
                 if (mu + 1 < p.M) {                 // scalar: both rows of the pair inside M
                     *reinterpret_cast<u32x4_t*>(dh) = hi;
-#ifdef VT_AB_NOLO
-                    asm volatile("" :: "v"(lo));
-#elif defined(VT_AB_LO8)   /* tuning builds only: an 8-byte store in place of the 16-byte one (timing of a 3-B format) */
-                    *reinterpret_cast<uint2*>(dl) = make_uint2(lo[0], lo[1]);
-#else
                     *reinterpret_cast<u32x4_t*>(dl) = lo;
-#endif
                     if (cst) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dc), "v"(v4) : "memory");
                 } else if (mu + rsub < p.M) {       // the last row of an odd M
                     *reinterpret_cast<u32x4_t*>(dh) = hi;
@@ -588,11 +408,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // place of an acquire (MI355X guide, "Valid forms": one signalling lane per workgroup after every
         // storing wave's vmcnt(0); one 128-KiB-LDS workgroup per CU; 16-B sc1 stores and 16-B sc1 loads, both in that row); no dispatch
         // order, timing or placement is assumed. The counter is left at zero for the next launch.
-#ifdef VT_AB_NOFINALIZE      /* tuning builds only: what the in-kernel finalize costs */
-        if (false) {
-#else
         if (p.rowstat_out) {
-#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int* s_last = reinterpret_cast<int*>(smem);
@@ -661,8 +477,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             scale = (n0 < p.D) ? ATT_Q_SCALE : 1.0f;   // q * log2(e)/sqrt(64): scores in log2 units
         }
         if (!v_tile) {
-            if constexpr (VER == 2) g256_mainloop2<true>(p, smem, m0, n0, acc);
-            else g256_mainloop<true>(p, smem, m0, n0, acc);
+            g256_mainloop2<true>(p, smem, m0, n0, acc);
             // whole tile as [256 rows][512 B]; 8-B chunk c8 of row r stored at c8 ^ ((r & 7) << 1)
             // folded LayerNorm (vt_common.hpp): y = a_r * acc + (b_r * colsum[n] + bias[n]); without one
             // a_r = 1, b_r = 0 and fma(1, acc, bias) = acc + bias exactly
@@ -738,8 +553,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         } else if constexpr (EPI == EPI_QKV) {
             // V, transposed per head: Vt[b][h][d][t], t contiguous. Lane = d, registers = 4 tokens.
-            if constexpr (VER == 2) g256_mainloop2<false>(p, smem, m0, n0, acc);
-            else g256_mainloop<false>(p, smem, m0, n0, acc);
+            g256_mainloop2<false>(p, smem, m0, n0, acc);
             const int heads = p.D >> 6;
             const bool ln = p.rowstat != nullptr;
             float bias_[2][2], cs_[2][2];
@@ -895,19 +709,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
     // and dropped the alternative of an XCD OWNING a column group and a quarter of its tiles for the whole
     // launch - W panels resident in its L2, every A panel fetched by one XCD per group: fc1 at 30 streams
     // 105.7 us against 100.5 with this dealing, ViT-L fc1 283 against 286: profiles/r03_tile_order_ab.txt.)
-#ifdef VT_AB_OWN     /* tuning builds only: an XCD owns a column group and a contiguous share of its tiles */
-    const int groups_ = (p.N >> 8) / cgw, xpg_ = 8 / (groups_ > 0 && groups_ <= 8 && 8 % groups_ == 0 ? groups_ : 8);
-    const int per_x_ = (per_group + xpg_ - 1) / xpg_;
-    const bool own_ = groups_ > 0 && groups_ <= 8 && 8 % groups_ == 0;
-    int seq = own_ ? (xcd / xpg_) * per_group + (xcd % xpg_) * per_x_ + slot : xcd * 32 + slot;
-    const int seq_step = own_ ? 32 : 8 * 32;
-    const int own_end_ = (xcd / xpg_) * per_group + ((xcd % xpg_ + 1) * per_x_ < per_group ? (xcd % xpg_ + 1) * per_x_ : per_group);
-    const int seq_end = own_ ? own_end_ : tiles;
-#else
     int seq = xcd * 32 + slot;                 // round 0: chunk xcd
     const int seq_step = 8 * 32;               // next round: chunk + 8
     const int seq_end = tiles;
-#endif
     (void)per_round;
     int m0 = 0, n0 = 0;
     bool after16 = false;
@@ -1125,12 +929,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
 // L2 (MI355X guide, "stores of each flavour"), and a round's 32 output tiles per XCD are 4.2 MB - as much as the
 // round's operand tiles - pushed through a 4-MiB L2 that the 32 CUs are re-reading those operands from.
 // Round 4, alternating builds in one process (profiles/r04_fc1_tile_order_cache_policy.txt): fc1 100.5 -> 96.3 us,
-// QKV 70.8 -> 69.4 us, ViT-L fc1 281.5 -> 277.2 us; fabric reads 151.7 -> 145.5 MB. VT_AB_PLAINOUT: the old form.
-#ifndef VT_AB_PLAINOUT
+// QKV 70.8 -> 69.4 us, ViT-L fc1 281.5 -> 277.2 us; fabric reads 151.7 -> 145.5 MB.
 #define G256P_ST16(PTR, V) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(PTR), "v"(V) : "memory")
-#else
-#define G256P_ST16(PTR, V) *reinterpret_cast<u32x4_t*>(PTR) = (V)
-#endif
 #define G256P_STORE(KB)                                                                           \
     lds_wait2_asm(o0, o1);                                                                       \
     if (full) {                                                                                  \
@@ -1140,11 +940,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs p, int tiles, in
         if ((KB) * 16 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2) * ostride8) = o0; \
         if ((KB) * 16 + 8 + rr < rows_left) *reinterpret_cast<u32x4_t*>(obase + (size_t)((KB) * 2 + 1) * ostride8) = o1; \
     }
-#ifdef VT_AB_SCALAR_GELU      /* tuning builds only: the per-element form, for A/B against the packed one */
-#define VT_GELU2X4(V) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) V[e_] = f32v2_t{gelu_erf(V[e_].x), gelu_erf(V[e_].y)}; }
-#else
 #define VT_GELU2X4(V) gelu_erf2x4(V)
-#endif
 // the four 2 x 2-element groups of a block are computed FIRST and written to LDS afterwards: an asm statement is
 // a scheduling fence, and with one ds_write per group hipcc had only that group's two dependent chains to
 // interleave - 218 s_nop (packed-fma result -> next packed fma, v_exp -> use) per tile and wave in a section
@@ -1322,22 +1118,23 @@ hipError_t launch_persistent(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 hipError_t prepare_one() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 2>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
 }
 
 template <int EPI>
-hipError_t launch_one(const GemmArgs& a, int ver, hipStream_t st) {
+hipError_t launch_one(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + 255) / 256) * (a.N / 256);
-    if (ver == 2) vt_launch((gemm256_kernel<EPI, 2>), dim3(tiles), dim3(512), G256_LDS, st, a);
-    else vt_launch((gemm256_kernel<EPI, 1>), dim3(tiles), dim3(512), G256_LDS, st, a);
+    vt_launch((gemm256_kernel<EPI>), dim3(tiles), dim3(512), G256_LDS, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
+
+#ifndef VT_TU_SHA256
+#define VT_TU_SHA256 "unstamped"
+#endif
+const char* gemm256_build_id() { return VT_TU_SHA256; }
 
 hipError_t gemm256_prepare() {
     hipError_t e;
@@ -1376,25 +1173,24 @@ bool gemm256_fits(const GemmArgs& a, int epilogue) {
 }
 
 // hipErrorInvalidValue: the shape does not fit this kernel
-hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st) {
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool persistent, hipStream_t st) {
     if (!gemm256_fits(a, epilogue)) return hipErrorInvalidValue;
-    if (ver == 3) {   // persistent: bf16 outputs, more tiles than CUs
+    if (persistent) {   // bf16 outputs, more tiles than CUs; anything else takes the one-tile-per-workgroup form
         const int tiles = ((a.M + 255) / 256) * (a.N / 256);
-        if (tiles <= 256) ver = 2;
-        else if (a.rowstat && (a.M & 1)) ver = 2;     // the row terms are fetched two rows per lane (16-B LDS-DMA)
-        else switch (epilogue) {
-            case EPI_GELU_BF16: return launch_persistent<EPI_GELU_BF16>(a, st);
-            case EPI_RELU_BF16: return launch_persistent<EPI_RELU_BF16>(a, st);
-            case EPI_QKV: return launch_persistent<EPI_QKV>(a, st);
-            default: ver = 2; break;
-        }
+        if (tiles > 256 && !(a.rowstat && (a.M & 1)))     // the row terms are fetched two rows per lane (16-B LDS-DMA)
+            switch (epilogue) {
+                case EPI_GELU_BF16: return launch_persistent<EPI_GELU_BF16>(a, st);
+                case EPI_RELU_BF16: return launch_persistent<EPI_RELU_BF16>(a, st);
+                case EPI_QKV: return launch_persistent<EPI_QKV>(a, st);
+                default: break;
+            }
     }
     switch (epilogue) {
-        case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, ver, st);
-        case EPI_RESID: return launch_one<EPI_RESID>(a, ver, st);
-        case EPI_GELU_BF16: return launch_one<EPI_GELU_BF16>(a, ver, st);
-        case EPI_RELU_BF16: return launch_one<EPI_RELU_BF16>(a, ver, st);
-        case EPI_QKV: return launch_one<EPI_QKV>(a, ver, st);
-        default: return launch_one<EPI_F32>(a, ver, st);
+        case EPI_F32_POS: return launch_one<EPI_F32_POS>(a, st);
+        case EPI_RESID: return launch_one<EPI_RESID>(a, st);
+        case EPI_GELU_BF16: return launch_one<EPI_GELU_BF16>(a, st);
+        case EPI_RELU_BF16: return launch_one<EPI_RELU_BF16>(a, st);
+        case EPI_QKV: return launch_one<EPI_QKV>(a, st);
+        default: return launch_one<EPI_F32>(a, st);
     }
 }

@@ -87,6 +87,7 @@ __device__ __forceinline__ u32x4_t gload_b128_asm(const void* p) {
 
 // sum over the four lanes of a quad (lanes 4k .. 4k+3), every lane gets the same bits: two DPP
 // quad_perm moves, no LDS traffic
+// (full EXEC required: see half_wave_sum in vt_common.hpp)
 __device__ __forceinline__ float quad_sum(float v) {
     const float a = v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     return a + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
@@ -97,9 +98,6 @@ __device__ __forceinline__ float quad_sum(float v) {
 // covers (quad-uniform: the four lanes of a quad hold the four 8-column groups of one chunk of one row),
 // and the bf16 pair. Fixed summation order -> run-to-run identical.
 __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, float& m2) {
-#ifdef VT_AB_NOSTATS      /* tuning builds only: what the statistics cost */
-    sum = x[0]; m2 = x[1]; return;
-#endif
     float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     s = quad_sum(s);
     const float mc = s * (1.0f / VT_STAT_CHUNK);
@@ -111,10 +109,6 @@ __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, f
 }
 __device__ __forceinline__ void x_split8(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
     uint32_t h[4], l[4];
-#ifdef VT_AB_NOSPLIT      /* tuning builds only: what the second half of the pair costs */
-    for (int e = 0; e < 4; ++e) { h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]); l[e] = 0; }
-    hi = u32x4_t{h[0], h[1], h[2], h[3]}; lo = u32x4_t{l[0], l[1], l[2], l[3]}; return;
-#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);

@@ -231,6 +231,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t st) {
 // band's last cell and stores nothing for them. TAIL: + logits + decode (needs BN = N = C).
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), every lane gets the same bits: two quad_perm moves,
 // row_half_mirror, row_mirror - no LDS round trip (a ds_bpermute butterfly was 20 dependent LDS trips per cell group)
+// (full EXEC required for row16_sum / row8_sum: see half_wave_sum in vt_common.hpp)
 __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
@@ -825,6 +826,17 @@ bool headconv_supported(int grid, int C, int N, int K, bool conv3x3) {
     if (grid < 1 || grid > 16 * HC_MBMAX) return false;
     if (conv3x3) return (C == 64 || C == 128) && N == C && K == 9 * C;
     return (N == 64 || N == 128) && K % 64 == 0 && K >= 64;
+}
+
+// supported AND plannable: some band height fits LDS for this layer (3x3 at C = 128 and maps of roughly 84..112 cells
+// per row: the halo image beside the 96-KiB ring, or the tail's 84-KiB floor, exceeds 160 KiB even at R = 1). The engine
+// asks this for all three layer kinds before it routes the head to this kernel; a shape that fails takes the
+// implicit-GEMM head.
+bool headconv_plannable(int grid, int C, int N, int K, bool conv3x3, bool tail) {
+    if (!headconv_supported(grid, C, N, K, conv3x3) || (tail && !conv3x3)) return false;
+    int R = 0, ncb = 0;
+    headconv_plan(1, grid, C, N, K, conv3x3, tail, false, &R, &ncb);
+    return R > 0;
 }
 
 // the 1x1 layer with the final LayerNorm inside (a.xh / a.xl / a.ln_g / a.ln_b set): D = 768 or 1024, and a band of at

@@ -13,6 +13,8 @@
 //
 // Float op order is fixed (this file is compiled with -ffp-contract=off and correctly rounded
 // sqrt/div) and identical to oracle/vt_oracle.c, so the outputs agree bit for bit.
+#include <algorithm>
+
 #include "vt_common.hpp"
 
 // /root/reference/src/nv12_convert.rs:24-29 (table entries) and :124-131 (per pixel)
@@ -31,43 +33,47 @@ __device__ __forceinline__ void yuv_to_rgb(int y, int u, int v, int& r, int& g, 
 }
 
 // One lane converts 4 horizontally adjacent pixels (two UV pairs). Packed NV12, stride == width
-// (src/nv12_convert.rs:53-54,105-106).
+// (src/nv12_convert.rs:53-54,105-106). g: index of the 4-pixel group in the frame, row-major.
+__device__ __forceinline__ void nv12_rgb_group4(const uint8_t* __restrict__ nv12, int w, int h, uint8_t* __restrict__ rgb,
+                                                long g, int groups_per_row) {
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)w * h;
+    const int row = (int)(g / groups_per_row);
+    const int col0 = (int)(g % groups_per_row) * 4;
+    const size_t yrow = (size_t)row * w;
+    const size_t uvrow = (size_t)(row >> 1) * w;
+    if (col0 + 3 < w && ((w & 3) == 0)) {
+        // aligned fast path: 4 B of Y, 4 B of UV, 12 B out
+        const uint32_t y4 = *reinterpret_cast<const uint32_t*>(yp + yrow + col0);
+        const uint32_t uv4 = *reinterpret_cast<const uint32_t*>(uvp + uvrow + col0);
+        int r[4], gg[4], b[4];
+        yuv_to_rgb(y4 & 255, uv4 & 255, (uv4 >> 8) & 255, r[0], gg[0], b[0]);
+        yuv_to_rgb((y4 >> 8) & 255, uv4 & 255, (uv4 >> 8) & 255, r[1], gg[1], b[1]);
+        yuv_to_rgb((y4 >> 16) & 255, (uv4 >> 16) & 255, uv4 >> 24, r[2], gg[2], b[2]);
+        yuv_to_rgb(y4 >> 24, (uv4 >> 16) & 255, uv4 >> 24, r[3], gg[3], b[3]);
+        uint32_t* o = reinterpret_cast<uint32_t*>(rgb + (yrow + col0) * 3);
+        o[0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+        o[1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+        o[2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+    } else {
+        for (int c = col0; c < min(col0 + 4, w); ++c) {
+            // UV pair of column (c & ~1): src/nv12_convert.rs:111-113 and the odd tail :152
+            const int u = uvp[uvrow + (c & ~1)], v = uvp[uvrow + (c & ~1) + 1];
+            int r, gg, b;
+            yuv_to_rgb(yp[yrow + c], u, v, r, gg, b);
+            uint8_t* o = rgb + (yrow + c) * 3;
+            o[0] = (uint8_t)r; o[1] = (uint8_t)gg; o[2] = (uint8_t)b;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nv12_to_rgb8_kernel(const uint8_t* __restrict__ nv12, int w,
                                                            int h, uint8_t* __restrict__ rgb) {
     const int groups_per_row = (w + 3) >> 2;
     const long total = (long)groups_per_row * h;
-    const uint8_t* yp = nv12;
-    const uint8_t* uvp = nv12 + (size_t)w * h;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(g / groups_per_row);
-        const int col0 = (int)(g % groups_per_row) * 4;
-        const size_t yrow = (size_t)row * w;
-        const size_t uvrow = (size_t)(row >> 1) * w;
-        if (col0 + 3 < w && ((w & 3) == 0)) {
-            // aligned fast path: 4 B of Y, 4 B of UV, 12 B out
-            const uint32_t y4 = *reinterpret_cast<const uint32_t*>(yp + yrow + col0);
-            const uint32_t uv4 = *reinterpret_cast<const uint32_t*>(uvp + uvrow + col0);
-            int r[4], gg[4], b[4];
-            yuv_to_rgb(y4 & 255, uv4 & 255, (uv4 >> 8) & 255, r[0], gg[0], b[0]);
-            yuv_to_rgb((y4 >> 8) & 255, uv4 & 255, (uv4 >> 8) & 255, r[1], gg[1], b[1]);
-            yuv_to_rgb((y4 >> 16) & 255, (uv4 >> 16) & 255, uv4 >> 24, r[2], gg[2], b[2]);
-            yuv_to_rgb(y4 >> 24, (uv4 >> 16) & 255, uv4 >> 24, r[3], gg[3], b[3]);
-            uint32_t* o = reinterpret_cast<uint32_t*>(rgb + (yrow + col0) * 3);
-            o[0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
-            o[1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
-            o[2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
-        } else {
-            for (int c = col0; c < min(col0 + 4, w); ++c) {
-                // UV pair of column (c & ~1): src/nv12_convert.rs:111-113 and the odd tail :152
-                const int u = uvp[uvrow + (c & ~1)], v = uvp[uvrow + (c & ~1) + 1];
-                int r, gg, b;
-                yuv_to_rgb(yp[yrow + c], u, v, r, gg, b);
-                uint8_t* o = rgb + (yrow + c) * 3;
-                o[0] = (uint8_t)r; o[1] = (uint8_t)gg; o[2] = (uint8_t)b;
-            }
-        }
-    }
+         g += (long)gridDim.x * blockDim.x)
+        nv12_rgb_group4(nv12, w, h, rgb, g, groups_per_row);
 }
 
 // Wide variant for w % 16 == 0 (1080p: 1920, 4K: 3840): one lane converts a 16 x 2 pixel block - the
@@ -76,43 +82,110 @@ __global__ __launch_bounds__(256) void nv12_to_rgb8_kernel(const uint8_t* __rest
 // (48 B of RGB per row): every access is a full dwordx4 and a wave touches 1 KiB of contiguous Y /
 // 3 KiB of contiguous RGB per row, against 4-B loads and 12-B stores in the general kernel (measured
 // there: 2.4 TB/s at 1080p, 3.8 TB/s at 4K of the ~6.3 TB/s a copy reaches). Same integer arithmetic.
+// g: index of the 16 x 2 block in the frame (bpr = w / 16 blocks per row pair). NT: the RGB stores bypass the
+// caches (a batch of frames is written once and read by somebody else).
+template <bool NT>
+__device__ __forceinline__ void nv12_rgb_block16x2(const uint8_t* __restrict__ nv12, int w, int h, uint8_t* __restrict__ rgb,
+                                                   long g, int bpr) {
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)w * h;
+    const int rp = (int)(g / bpr), col0 = (int)(g % bpr) << 4;
+    const uint4 uv = *reinterpret_cast<const uint4*>(uvp + (size_t)rp * w + col0);
+    const uint32_t uvw[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+        const int row = 2 * rp + r2;
+        if (row >= h) break;                  // odd height: the last pair has one row
+        const uint4 y4 = *reinterpret_cast<const uint4*>(yp + (size_t)row * w + col0);
+        const uint32_t yw[4] = {y4.x, y4.y, y4.z, y4.w};
+        uint32_t o[12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {         // 4 pixels = one Y dword and one UV dword (2 pairs)
+            int r[4], gg[4], b[4];
+            const int u0 = uvw[q] & 255, v0 = (uvw[q] >> 8) & 255, u1 = (uvw[q] >> 16) & 255, v1 = uvw[q] >> 24;
+            yuv_to_rgb(yw[q] & 255, u0, v0, r[0], gg[0], b[0]);
+            yuv_to_rgb((yw[q] >> 8) & 255, u0, v0, r[1], gg[1], b[1]);
+            yuv_to_rgb((yw[q] >> 16) & 255, u1, v1, r[2], gg[2], b[2]);
+            yuv_to_rgb(yw[q] >> 24, u1, v1, r[3], gg[3], b[3]);
+            o[3 * q + 0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+            o[3 * q + 1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+            o[3 * q + 2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+        }
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(rgb + ((size_t)row * w + col0) * 3);
+        const u32x4_t s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]}, s2 = {o[8], o[9], o[10], o[11]};
+        if (NT) {
+            __builtin_nontemporal_store(s0, dst); __builtin_nontemporal_store(s1, dst + 1); __builtin_nontemporal_store(s2, dst + 2);
+        } else {
+            dst[0] = s0; dst[1] = s1; dst[2] = s2;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nv12_to_rgb8_wide_kernel(const uint8_t* __restrict__ nv12, int w,
                                                                 int h, uint8_t* __restrict__ rgb) {
     const int bpr = w >> 4;                       // 16-pixel blocks per row
-    const int row_pairs = (h + 1) >> 1;
-    const long total = (long)bpr * row_pairs;
-    const uint8_t* yp = nv12;
-    const uint8_t* uvp = nv12 + (size_t)w * h;
+    const long total = (long)bpr * ((h + 1) >> 1);
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (long)gridDim.x * blockDim.x) {
-        const int rp = (int)(g / bpr), col0 = (int)(g % bpr) << 4;
-        const uint4 uv = *reinterpret_cast<const uint4*>(uvp + (size_t)rp * w + col0);
-        const uint32_t uvw[4] = {uv.x, uv.y, uv.z, uv.w};
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const int row = 2 * rp + r2;
-            if (row >= h) break;                  // odd height: the last pair has one row
-            const uint4 y4 = *reinterpret_cast<const uint4*>(yp + (size_t)row * w + col0);
-            const uint32_t yw[4] = {y4.x, y4.y, y4.z, y4.w};
-            uint32_t o[12];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {         // 4 pixels = one Y dword and one UV dword (2 pairs)
-                int r[4], gg[4], b[4];
-                const int u0 = uvw[q] & 255, v0 = (uvw[q] >> 8) & 255, u1 = (uvw[q] >> 16) & 255, v1 = uvw[q] >> 24;
-                yuv_to_rgb(yw[q] & 255, u0, v0, r[0], gg[0], b[0]);
-                yuv_to_rgb((yw[q] >> 8) & 255, u0, v0, r[1], gg[1], b[1]);
-                yuv_to_rgb((yw[q] >> 16) & 255, u1, v1, r[2], gg[2], b[2]);
-                yuv_to_rgb(yw[q] >> 24, u1, v1, r[3], gg[3], b[3]);
-                o[3 * q + 0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
-                o[3 * q + 1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
-                o[3 * q + 2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+         g += (long)gridDim.x * blockDim.x)
+        nv12_rgb_block16x2<false>(nv12, w, h, rgb, g, bpr);
+}
+
+// ---- n frames per launch (vt_nv12_to_rgb8_batch_device) ------------------------------------------------------------
+// A host that still wants RGB for all its cameras (the reference converts every frame, src/pipeline.rs:105) pays one
+// launch ramp per call, not per frame: a single 1080p conversion is a 3.9-us kernel bounded by that ramp (0.29 of the HBM
+// roof), a batch of 30 is one 280-MB stream. The frame table travels in the kernel arguments; in[i] == nullptr = the
+// reference's all-zero frame for a short buffer (src/nv12_convert.rs:48-50). Same per-pixel arithmetic (the functions above).
+template <bool WIDE>
+__global__ __launch_bounds__(256) void nv12_to_rgb8_batch_kernel(Nv12Batch bt, int n, int w, int h) {
+    const int per_row = WIDE ? (w >> 4) : ((w + 3) >> 2);
+    const long per_frame = (long)per_row * (WIDE ? ((h + 1) >> 1) : h);
+    const long total = per_frame * n;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(g / per_frame);
+        const long gl = g - (long)f * per_frame;
+        const uint8_t* src = bt.in[f];
+        uint8_t* dst = bt.out[f];
+        if (src == nullptr) {                       // short buffer: zero frame
+            if (WIDE) {
+                const int rp = (int)(gl / per_row), col0 = (int)(gl % per_row) << 4;
+                const u32x4_t z = {0u, 0u, 0u, 0u};
+                for (int r2 = 0; r2 < 2 && 2 * rp + r2 < h; ++r2) {
+                    u32x4_t* o = reinterpret_cast<u32x4_t*>(dst + ((size_t)(2 * rp + r2) * w + col0) * 3);
+                    o[0] = z; o[1] = z; o[2] = z;
+                }
+            } else {
+                const int row = (int)(gl / per_row), col0 = (int)(gl % per_row) * 4;
+                for (int c = col0; c < min(col0 + 4, w); ++c) {
+                    uint8_t* o = dst + ((size_t)row * w + c) * 3;
+                    o[0] = 0; o[1] = 0; o[2] = 0;
+                }
             }
-            uint4* dst = reinterpret_cast<uint4*>(rgb + ((size_t)row * w + col0) * 3);
-            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-            dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+            continue;
         }
+        if (WIDE) nv12_rgb_block16x2<true>(src, w, h, dst, gl, per_row);
+        else nv12_rgb_group4(src, w, h, dst, gl, per_row);
     }
+}
+
+hipError_t launch_nv12_to_rgb8_batch(const uint8_t* const* d_in, uint8_t* const* d_out, int n, int w, int h, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += VT_NV12_BATCH_MAX) {
+        const int m = std::min(VT_NV12_BATCH_MAX, n - i0);
+        Nv12Batch bt{};
+        bool wide = (w % 16) == 0 && (((size_t)w * h) % 16) == 0;
+        for (int i = 0; i < m; ++i) {
+            bt.in[i] = d_in[i0 + i]; bt.out[i] = d_out[i0 + i];
+            wide = wide && (reinterpret_cast<uintptr_t>(bt.in[i]) % 16) == 0 && (reinterpret_cast<uintptr_t>(bt.out[i]) % 16) == 0;
+        }
+        const long per_frame = wide ? (long)(w >> 4) * ((h + 1) >> 1) : (long)((w + 3) >> 2) * h;
+        const long total = per_frame * m;
+        int blocks = (int)std::min<long>((total + 255) / 256, 256 * 8);       // 8 blocks per CU, grid-stride the rest
+        if (blocks < 1) blocks = 1;
+        if (wide) vt_launch(nv12_to_rgb8_batch_kernel<true>, dim3(blocks), dim3(256), 0, st, bt, m, w, h);
+        else vt_launch(nv12_to_rgb8_batch_kernel<false>, dim3(blocks), dim3(256), 0, st, bt, m, w, h);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st) {

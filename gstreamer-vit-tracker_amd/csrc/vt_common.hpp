@@ -113,15 +113,16 @@ hipError_t launch_gemm_cfg(const GemmArgs& a, int epilogue, int cfg, hipStream_t
 int gemm_pick_config(int M, int N, int K, int epilogue, bool conv = false);
 const char* gemm_config_name(int cfg);
 hipError_t gemm_prepare();  // once per device, before the first launch / any stream capture
-// k_gemm256.hip: the 256x256-tile 8-wave kernel (config 17); hipErrorInvalidValue = shape does not fit
+// k_gemm256.hip: the 256x256-tile 8-wave kernels (configs 18, 19); hipErrorInvalidValue = shape does not fit
 #define GEMM_CFG_SMALL_MAX 8   // 0..8: the 4-wave kernel of k_gemm.hip (7, 8 with four loader waves beside it)
-#define GEMM_CFG_256P8 17      // 4 phases of 16 MFMAs per K-tile (round 1)
-#define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile (schedule v2)
-#define GEMM_CFG_256PP 19      // v2, persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)
+#define GEMM_CFG_256P4 18      // 2 phases of 32 MFMAs per K-tile, one tile per workgroup (17, round 1's 4-phase schedule: git history)
+#define GEMM_CFG_256PP 19      // the same loop in persistent workgroups (bf16 outputs with more tiles than CUs; else = 18)
+#define GEMM_CFG_256_MIN GEMM_CFG_256P4
 // operands of the 256x256 kernels are addressed with unsigned 32-bit byte offsets from their base
 #define VT_GEMM256_MAX_OPERAND_BYTES (1ll << 32)
 hipError_t gemm256_prepare();
-hipError_t launch_gemm256(const GemmArgs& a, int epilogue, int ver, hipStream_t st);
+const char* gemm256_build_id();   // sha256 of k_gemm256.hip + the headers it includes + its compile flags (build.py: -DVT_TU_SHA256)
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool persistent, hipStream_t st);
 bool gemm256_fits(const GemmArgs& a, int epilogue);
 // the tile configuration launch_gemm() runs for these arguments (the picker's choice, or the 4-wave
 // kernel where a 256x256 choice does not fit the operands)
@@ -166,6 +167,11 @@ hipError_t launch_preproc(const FrameDesc* frames, StreamState* states, bf16_t* 
 int preproc_tier_for_box(const ModelDims& d, float w, float h, bool is_template);
 
 hipError_t launch_nv12_to_rgb8(const uint8_t* nv12, int w, int h, uint8_t* rgb, hipStream_t st);
+// n frames per launch: d_in[i] packed NV12 (nullptr: the all-zero frame of a short buffer), d_out[i] w*h*3 bytes; the
+// tables are HOST arrays of device pointers (they travel in the kernel arguments, VT_NV12_BATCH_MAX frames per launch)
+#define VT_NV12_BATCH_MAX 64
+struct Nv12Batch { const uint8_t* in[VT_NV12_BATCH_MAX]; uint8_t* out[VT_NV12_BATCH_MAX]; };
+hipError_t launch_nv12_to_rgb8_batch(const uint8_t* const* d_in, uint8_t* const* d_out, int n, int w, int h, hipStream_t st);
 
 
 hipError_t launch_overlay(uint8_t* yplane, int width, int height, int stride, const vt_draw_cmd* d_cmds,
@@ -221,6 +227,7 @@ struct HeadConvArgs {
 };
 bool headconv_supported(int grid, int C, int N, int K, bool conv3x3);
 bool headconv_ln_supported(int grid, int N, int D);
+bool headconv_plannable(int grid, int C, int N, int K, bool conv3x3, bool tail);   // supported and some band height fits LDS
 hipError_t headconv_prepare();     // once per device, before the first launch / any stream capture
 // dec != nullptr (3x3 layers only): the 5-logit layer, the score window, the argmax and the box decode run inside
 // the same launch (dec->t3 is ignored: the logits are computed from the layer's own output tile)
@@ -270,6 +277,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // banks 0 / 2 of a row take lane + 4, banks 1 / 3 lane - 4), two quad_perms. Same partners in the same order as
 // "for (off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off)" and therefore the same bits (tools/dpp_xor_check.hip), without
 // that form's five dependent LDS round trips (ds_bpermute) per sum.
+// PRECONDITION - FULL EXEC: every lane of the wave must be active at the call. A DPP / permlane source lane that is
+// masked off reads as 0 (bound_ctrl) or keeps the old value, so under divergence (`if (r < rows) ln_row(...)`) the sums
+// would silently miss terms. All callers keep the wave uniform: rows past the end are CLAMPED to the last row and only
+// the stores are guarded (k_misc.hip layernorm kernels, k_head.hip LNC path). The same holds for quad_sum / row16_sum /
+// row8_sum of k_gemm_util.hpp and k_head.hip. The s_nop counts inside the asm are the gfx950 wait states (VALU write ->
+// permlane read: 2; permlane write -> VALU read: 2) the compiler cannot check there; tools/dpp_xor_check.hip (run by
+// tests/test_gpu_ops.py on the box, built with the box's ROCm) guards both the workaround and those counts.
 __device__ __forceinline__ float half_wave_sum(float v) {
     // inline asm, not __builtin_amdgcn_permlane16_swap: on float operands hipcc (ROCm 7.2) adds the swap's FIRST result to
     // itself (the integer form compiles correctly; tools/dpp_xor_check.hip caught it). s_nop: VALU write -> permlane read

@@ -63,6 +63,15 @@ def gather_per_rank(local_value: float, device="cpu") -> list:
     return [float(local_value)]
 
 
+def gather_objects(obj) -> list:
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable records: CPU masks, plans)"""
+    if dist.is_available() and dist.is_initialized():
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, obj)
+        return parts
+    return [obj]
+
+
 def shard_streams(n_streams: int, rank: int, world: int) -> list[int]:
     """Global stream ids owned by `rank` (round-robin; no data moves between ranks)."""
     return list(range(rank, n_streams, world))

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 4   /* 4: vt_config.host_zero_copy (a former reserved slot: zero = the old default for single trackers), vt_group_set_tuning, vt_op_headconv_bf16, vt_op_headconv_ln_bf16 - additions only, a host built against 3 keeps working; 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
+#define VT_ABI_VERSION 5   /* 5: vt_nv12_to_rgb8_batch_device, vt_group_graph_captures; the operator-level test hooks (vt_op_*) moved to vittrack_hip_ops.h / libvittrack_hip_ops.so - the product library exports this header's symbols only; 4: vt_config.host_zero_copy (a former reserved slot: zero = the old default for single trackers), vt_group_set_tuning, vt_op_headconv_bf16, vt_op_headconv_ln_bf16 - additions only, a host built against 3 keeps working; 3: vt_op_gemm_bf16 / vt_op_qkv_bf16 take folded-LayerNorm terms; 2: vt_frame.window_w/h, vt_config.max_device_mib, explicit cfg/mode on vt_op_* */
 
 typedef enum vt_status {
     VT_OK = 0,
@@ -104,6 +104,10 @@ typedef struct vt_group vt_group;     /* B independent streams batched on one GP
 void vt_config_default(vt_config* cfg);
 const char* vt_last_error(void);       /* thread-local text of the last failure */
 int vt_abi_version(void);
+/* "abi=5;k_gemm256=<sha256>;..." - identity of this build: the ABI version and, per kernel translation unit that a
+ * committed measurement refers to, the sha256 over its sources and compile flags that build.py stamped into it
+ * (bench.py ties profiles/r06_dominant_kernel_pmc.json to the kernel that is running through it). Static string. */
+const char* vt_build_info(void);
 int vt_device_count(void);             /* gfx950 devices visible; 0 → vt_create fails */
 /* Streams per vt_group that fill the MI355X's 256 CUs in whole rounds of the 256x256 GEMM kernel
  * (the smallest batch <= max_streams whose worst encoder GEMM wastes < 2 % of its rounds; 1 if
@@ -253,6 +257,11 @@ int vt_group_enqueue_host(vt_group* g, const vt_frame* host_frames, int n);
 int vt_group_wait_next(vt_group* g, vt_result* out, int n);
 /* passes vt_group_wait_next had to redo because a speculative window missed (since creation) */
 int vt_group_host_redos(const vt_group* g);
+/* hipGraph captures this engine has made since creation. The pass is replayed as a captured graph, one per
+ * crop-buffer tier; all of them are captured and instantiated when the engine is created (and again by
+ * vt_group_set_tuning), never inside an enqueue: a live 60-fps stream (src/pipeline.rs:26-37) whose target grows
+ * across a tier boundary takes no capture stall mid-track. Constant after creation unless the tuning is changed. */
+int vt_group_graph_captures(const vt_group* g);
 
 /* ---- dma-buf ingest ------------------------------------------------------------------------
  * The reference's capture side can hand out dma-bufs (v4l2src io-mode=dmabuf, src/pipeline_ir.rs:24)
@@ -300,6 +309,16 @@ int vt_nv12_to_rgb8(int device_id, const uint8_t* nv12, size_t len, int w, int h
 /* device-pointer form (d_rgb_out: w*h*3 bytes); enqueued on hip_stream (NULL → default) */
 int vt_nv12_to_rgb8_device(int device_id, const void* d_nv12, size_t len, int w, int h,
                            void* d_rgb_out, void* hip_stream);
+
+/* n frames per launch (a host that still wants RGB for all its cameras: the reference converts every frame,
+ * src/pipeline.rs:105): frame i is d_nv12[i] (packed NV12 of lens[i] bytes, as above) -> d_rgb_out[i] (w*h*3 bytes);
+ * all frames w x h. d_nv12 / lens / d_rgb_out are HOST arrays of n entries holding DEVICE pointers; they are consumed
+ * before the call returns. Per frame bit-exact with vt_nv12_to_rgb8_device, including the all-zero frame for
+ * lens[i] < w*h*3/2; VT_ERR_SHORT_BUFFER (nothing enqueued) if some lens[i] does not cover the conversion's reads.
+ * One launch per 64 frames, enqueued on hip_stream (NULL -> default). A single 1080p conversion is a 3.9-us launch
+ * bounded by its ramp-up (0.29 of the HBM roof); 30 frames in one launch stream at the rate DESIGN.md section 4 gives. */
+int vt_nv12_to_rgb8_batch_device(int device_id, const void* const* d_nv12, const size_t* lens, int n, int w, int h,
+                                 void* const* d_rgb_out, void* hip_stream);
 
 /* ---- overlay drawing on the GPU (the reference's per-frame overlays) --------------------------- */
 
@@ -379,79 +398,11 @@ int vt_group_set_state_box(vt_group* g, int stream, const float* box4);
  * both need taps), "x" [N,D] (final residual stream; like the taps the sum of the bf16 pair it is stored
  * as), "rowstat" [N,2] (row terms of the last folded LayerNorm), "attn" [N,D] (last block's attention output),
  * "feat" [Ns,D], "head_t3" [Ns,C], "head_out" [Ns,8] (score,ox,oy,w,h logits),
- * "state" (the stream's device state record as raw 32-bit words).
+ * "state" (the stream's device state record as raw 32-bit words), "graph_replays" [3] (passes replayed so far
+ * per crop-buffer tier: which of the captured graphs ran).
  * Returns the element count, or a negative vt_status. With out == NULL only the count. */
 int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* out,
                              int64_t capacity);
-
-/* ---- operator-level entry points (numerics tests call the same kernels the pass uses) ---- */
-
-/* acc[M,N] = A[M,K] (bf16 bits) x W[N,K]^T (bf16 bits), float32 accumulation. Host pointers.
- * K % 64 == 0, N % 64 == 0. cfg: tile configuration as in vt_op_gemm_bench (< 0: the launcher's own
- * choice for the shape). epilogue:
- *   0  x = acc + bias                    the X-epilogues the engine keeps its residual stream with: x is
- *   1  x = (acc + bias) + c_inout        stored as a bf16 pair (hi = bf16(x), lo = bf16(x - hi)) and comes
- *   4  x = (acc + bias) + pos            back as hi + lo (17 significant bits); pos = c_inout, one row per
- *                                        output row. rowstat_out (may be NULL) receives per row the terms
- *                                        (rstd, -mean * rstd) of LayerNorm(x) with `eps`, computed from the
- *                                        float32 x before the split (what the consuming GEMM multiplies with).
- *   2  GELU(y) -> bf16, 3  ReLU(y) -> bf16 (returned widened to f32); y = acc + bias, or with a folded
- *      LayerNorm (rowstat_in [M][2] and colsum [N] not NULL): y = rowstat_in[m][0] * acc +
- *      (rowstat_in[m][1] * colsum[n] + bias[n]). */
-int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                    float* c_inout, int M, int N, int K, int epilogue, int cfg,
-                    const float* rowstat_in, const float* colsum, float* rowstat_out, float eps);
-/* Kernel-tuning helper: mean microseconds per launch of the GEMM kernel on device-resident random
- * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
- * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2
- * (K-tile depth 64); 4 = 64x64 ring 3, 5 = 64x64 ring 2, 6 = 128x128 ring 2 (K-tile depth 128, K % 128 == 0);
- * 17 / 18 / 19 = 256x256 8-wave kernels; <0 = the launcher's own choice. */
-int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
-                     float* us_out);
-/* The head's 3x3 convolution (zero padding) + bias + ReLU as the engine runs it - an implicit GEMM whose
- * A loads gather the im2col row: t [B*grid*grid][C] bf16, w [N][9*C] bf16 (column (ky*3+kx)*C + c),
- * out [B*grid*grid][N] (bf16 widened to f32). C % 64 == 0, N % 64 == 0; cfg 0..6 (4..6: C % 128 == 0), < 0: launcher's choice. */
-int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias,
-                            float* out, int B, int grid, int C, int N, int cfg);
-/* The head's band kernel (csrc/k_head.hip) on its own: out = relu(conv(t) + bias). conv3x3 != 0: t [B*grid*grid][Cin],
- * w [N][9*Cin] (column (ky*3+kx)*Cin + c), N == Cin, zero padding; else the 1x1 layer, w [N][Cin]. R (rows of the
- * map per workgroup) / ncb (16-column blocks per wave) <= 0: the launcher's plan. t == NULL: operands filled with a
- * fixed pseudo-random pattern (timing runs). out (nullable): bf16 values widened to f32. iters > 0 and us_out: mean
- * microseconds per launch. */
-int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
-                        int B, int grid, int Cin, int N, int conv3x3, int R, int ncb, int iters, float* us_out);
-/* The head's first (1x1) layer with the final LayerNorm in front of it: out[b*grid*grid + cell][n] =
- * relu(LayerNorm(xh + xl)[b*ntok + off + cell] . w[n] + bias[n]); xh / xl [B*ntok][D] the bf16 pair of the residual
- * stream, gamma / beta [D], w [N][D], D = 768 or 1024. fused != 0: ONE launch - the band kernel normalises its band's
- * rows itself (what the engine runs); fused == 0: the LayerNorm kernel, then the band kernel on its output - the fused
- * form reproduces it bit for bit. R / ncb / iters / us_out / out as above; xh == NULL: synthetic operands (timing). */
-int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl, const float* gamma, const float* beta,
-                           float eps, int ntok, int off, const uint16_t* w, const float* bias, float* out, int B, int grid,
-                           int D, int N, int fused, int R, int ncb, int iters, float* us_out);
-/* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->
- * qk_out [B*tokens, 2D] (q scaled by 1/8, then k) and vt_out [B*H, 64, npad] (v transposed per head,
- * npad = tokens rounded up to 64, padding zero); bf16 results widened to f32. cfg as above;
- * vt_perm = 1: Vt in the key order attention mode 3 reads (attn_perm16 inside every 16 keys).
- * rowstat_in [B*tokens][2] / colsum [3D] (both or neither NULL): a folded LayerNorm as in vt_op_gemm_bf16. */
-int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias,
-                   float* qk_out, float* vt_out, int B, int tokens, int D, int cfg, int vt_perm,
-                   const float* rowstat_in, const float* colsum);
-/* out[B,N,H*64] (bf16 widened to f32) = softmax(q k^T) v per head; q,k,v: [B,N,H*64] bf16 bits
- * (q already scaled). mode as in vt_op_attention_bench. */
-int vt_op_attention_bf16(int device_id, const uint16_t* q, const uint16_t* k, const uint16_t* v,
-                         float* out, int B, int N, int H, int mode);
-/* Kernel-tuning helper: mean microseconds per launch of the attention kernel on random data;
- * mode 0 key-split, 1 independent waves, 2 LDS-shared tiles, 3 LDS-DMA ring (permuted Vt),
- * <0 the launcher's choice. */
-int vt_op_attention_bench(int device_id, int B, int N, int H, int mode, int iters, float* us_out);
-/* Kernel-timing helper: mean microseconds per launch of the whole-frame NV12 -> RGB8 converter
- * (the reference's nv12_full_to_rgb_parallel, src/nv12_convert.rs:46-92) on a device-resident
- * w x h frame of random bytes (HIP events around `iters` launches). Algorithmic traffic is
- * 1.5 + 3 bytes per pixel. */
-int vt_op_nv12_to_rgb8_bench(int device_id, int w, int h, int iters, float* us_out);
-/* y[M,D] (bf16 widened) = LayerNorm(x[M,D] f32; gamma, beta, eps=1e-6) */
-int vt_op_layernorm(int device_id, const float* x, const float* gamma, const float* beta,
-                    float* y, int M, int D);
 
 #ifdef __cplusplus
 }

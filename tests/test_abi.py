@@ -13,6 +13,13 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(vth?_[a-z0-9_]+)\s*\(", txt)))
 
 
+def _exported(path):
+    """dynamic symbols a shared library defines (nm -D --defined-only)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
 def test_hip_library_exports_every_declared_symbol(vt):
     names = _declared("vittrack_hip.h")
     assert len(names) >= 30
@@ -21,7 +28,32 @@ def test_hip_library_exports_every_declared_symbol(vt):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(vt.EXPORTS) == names
-    assert L.vt_abi_version() == 4
+    assert L.vt_abi_version() == 5
+
+
+def test_the_product_library_exports_the_boundary_and_nothing_else(vt):
+    """`nm -D libvittrack_hip.so` = the functions include/vittrack_hip.h declares: boundary, groups, ingest, converter,
+    overlays, RCCL broadcast, diagnostics. No kernel launcher, no engine internals, none of the operator-level test hooks
+    (vt_op_*: include/vittrack_hip_ops.h, libvittrack_hip_ops.so)."""
+    got = _exported(vt.LIB_PATH)
+    assert got == _declared("vittrack_hip.h"), sorted(set(got) ^ set(_declared("vittrack_hip.h")))
+    assert not [n for n in got if n.startswith("vt_op_")]
+    # the operator header declares only vt_op_* beyond what it includes, and the ops library carries all of them
+    ops = [n for n in _declared("vittrack_hip_ops.h") if n.startswith("vt_op_")]
+    assert sorted(vt.OPS_EXPORTS) == ops and len(ops) >= 10
+    assert os.path.exists(vt.OPS_LIB_PATH), "run python __graft_entry__.py first"
+    have = set(_exported(vt.OPS_LIB_PATH))
+    assert set(ops) <= have and set(_declared("vittrack_hip.h")) <= have
+    # the product path never touches it: no product source includes the ops header, bench.py and the harness call no vt_op_*
+    import glob
+    pkg = os.path.join(ROOT, "gstreamer-vit-tracker_amd")
+    for f in glob.glob(os.path.join(pkg, "csrc", "*")):
+        if os.path.basename(f) != "vt_ops.hip":
+            assert not re.search(r"#include[^\n]*vittrack_hip_ops", open(f).read()), f
+    for f in [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + glob.glob(os.path.join(ROOT, "harness", "*")):
+        if os.path.isfile(f) and not f.endswith((".so", "c_client")):
+            txt = open(f, errors="replace").read()
+            assert "ops_lib" not in txt and "vt.op_" not in txt and "vt_op_" not in txt and "vittrack_hip_ops" not in txt, f
 
 
 def test_host_library_exports_every_declared_symbol(vt):

@@ -89,6 +89,24 @@ def test_bench_self_launches_its_ranks_gloo_dry_run(vt, weights_tiny):
     assert d["per_rank_fps"] == pytest.approx([60.0, 40.0]) and d["value"] == pytest.approx(80.0)
     assert d["global_stream_ids_rank0"] == [0, 1, 2]
     assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    _check_masks(d, 2)
+
+
+def _check_masks(d, world):
+    """every rank pinned itself before torch / HIP loaded: the masks the ranks REALLY run under (sched_getaffinity
+    inside each rank, gathered) are disjoint, non-empty, and what the rank's own record says"""
+    from gstreamer_vit_tracker_amd import placement
+    masks = d["cpu_affinity_by_rank"]
+    assert [m["rank"] for m in masks] == list(range(world))
+    allowed = len(os.sched_getaffinity(0))
+    seen = set()
+    for m in masks:
+        cpus = set(m["running_on"])
+        assert cpus and m["n"] == len(cpus) and placement.parse_cpulist(m["cpus"]) == sorted(cpus)
+        if allowed >= world:
+            assert not (cpus & seen), masks
+        seen |= cpus
+    assert d["config"]["cpu_affinity"] == {k: masks[0][k] for k in ("cpus", "n", "source")}
 
 
 def test_externally_launched_ranks_set_the_ipc_mode_themselves(vt, weights_tiny):
@@ -111,6 +129,11 @@ def test_externally_launched_ranks_set_the_ipc_mode_themselves(vt, weights_tiny)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["collective"]["world_size"] == 2
     assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # BASELINE.json configs[3] (one stream per GPU): the N-rank line shape of `--streams 1 --groups 1`; literal only on 8 GPUs
+    assert d["config"]["streams_per_gpu"] == 1 and d["config"]["engines_per_gpu"] == 1
+    assert d["config"]["cfg4_shape"] is True and d["config"]["cfg4_literal"] is False
+    assert d["per_rank_fps"] == pytest.approx([8.0, 4 / 0.75]) and len(d["per_rank_fps"]) == 2
+    _check_masks(d, 2)
 
 
 def test_bench_launcher_does_not_touch_torch_in_the_parent_and_propagates_failure(vt):
@@ -129,6 +152,48 @@ def test_bench_launcher_does_not_touch_torch_in_the_parent_and_propagates_failur
                         "--workload", "tiny"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
     assert r.returncode != 0
     assert "needs 2 devices" in r.stderr, r.stderr[-3000:]
+
+
+def test_rank_cpu_masks_are_numa_local_and_disjoint(vt, tmp_path):
+    """placement.rank_cpu_mask on a made-up 8-GPU, 2-socket topology (sysfs tree under tmp_path): ranks 0-3 share
+    socket 0's CPUs, 4-7 socket 1's, every rank gets its own slice; restricted affinity and missing topology fall back
+    to slicing what is allowed"""
+    from gstreamer_vit_tracker_amd import placement as pl
+    assert pl.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and pl.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    sysfs = tmp_path / "sys"
+    # two CPU nodes (no SIMDs) then eight GPU nodes, as KFD lists them
+    for i in range(10):
+        nd = sysfs / "class/kfd/kfd/topology/nodes" / str(i)
+        nd.mkdir(parents=True)
+        gpu = i - 2
+        (nd / "properties").write_text(f"cpu_cores_count {64 if i < 2 else 0}\nsimd_count {0 if i < 2 else 1024}\n"
+                                       f"drm_render_minor {128 + gpu if i >= 2 else 0}\n")
+        if i >= 2:
+            dv = sysfs / f"class/drm/renderD{128 + gpu}/device"
+            dv.mkdir(parents=True)
+            (dv / "local_cpulist").write_text("0-63,128-191\n" if gpu < 4 else "64-127,192-255\n")
+    gl = pl.gpu_local_cpulists(str(sysfs))
+    assert len(gl) == 8 and gl[0] == pl.parse_cpulist("0-63,128-191") and gl[7] == pl.parse_cpulist("64-127,192-255")
+    allowed = list(range(256))
+    masks = [pl.rank_cpu_mask(r, 8, allowed, gl)[0] for r in range(8)]
+    assert all(len(m) == 32 for m in masks)
+    assert sorted(c for m in masks for c in m) == allowed                     # disjoint and complete
+    assert all(set(masks[r]) <= set(gl[r]) for r in range(8))                 # NUMA-local
+    # HIP_VISIBLE_DEVICES remaps local ranks to GPUs: rank 0 -> GPU 5 lives on socket 1
+    m0, src = pl.rank_cpu_mask(0, 2, allowed, gl, devmap=[5, 1])
+    assert set(m0) <= set(gl[5]) and "NUMA-local" in src
+    assert pl.visible_device_map({"HIP_VISIBLE_DEVICES": "5,1"}) == [5, 1] and pl.visible_device_map({"ROCR_VISIBLE_DEVICES": "GPU-abc"}) is None
+    # a cgroup that allows 16 CPUs of socket 0 only: rank on socket 1 has no local CPU -> everybody slices what is allowed
+    small = list(range(16))
+    ms = [pl.rank_cpu_mask(r, 8, small, gl)[0] for r in range(8)]
+    assert sorted(c for m in ms for c in m) == small and all(len(m) == 2 for m in ms)
+    # no topology at all
+    ms = [pl.rank_cpu_mask(r, 2, list(range(8)), [])[0] for r in range(2)]
+    assert ms == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert pl.rank_cpu_mask(0, 4, [3])[0] == [3]                               # fewer CPUs than ranks: shared
+    with pytest.raises(ValueError):
+        pl.rank_cpu_mask(2, 2, [0, 1])
+    assert pl.apply(0, 1)["source"].startswith("single rank")                 # N = 1: mask untouched
 
 
 def test_shard_streams_properties(vt):

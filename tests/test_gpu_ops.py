@@ -34,7 +34,7 @@ def test_gemm_f32(gpu, M, N, K):
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 18, 19])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_every_tile_config(gpu, cfg, epi):
     """each tile configuration (64x64 / 128x128 with ring 2..4 and K-tile depth 64, 4-6: depth 128,
@@ -56,7 +56,7 @@ def test_gemm_every_tile_config(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 18, 19])
 def test_qkv_every_tile_config(gpu, cfg):
     rng = np.random.default_rng(cfg)
     B, tokens, D = 2, 100, 768
@@ -104,10 +104,10 @@ def test_gemm_4wave_exact_integers(gpu, M, N, K, cfg):
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
-@pytest.mark.parametrize("cfg", [17, 18])
+@pytest.mark.parametrize("cfg", [18])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (256, 512, 256), (1000, 768, 1024), (513, 256, 192)])
 def test_gemm256_exact_integers(gpu, M, N, K, cfg):
-    """the 256x256 8-wave kernels (config 17: 4 phases per K-tile, 18: 2 long phases) on small-integer
+    """the 256x256 8-wave kernel (config 18: 2 long phases per K-tile, one tile per workgroup) on small-integer
     operands: every product and sum is exact, so any mis-staged half-tile, swizzle slip or early
     read of a buffer shows as a wrong integer; K = 128 is the shortest supported loop (prologue +
     the two tail tiles only), K = 192 runs the steady-state body exactly once"""
@@ -124,9 +124,9 @@ def test_gemm256_exact_integers(gpu, M, N, K, cfg):
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
 
-@pytest.mark.parametrize("cfg", [17, 18, 19])
+@pytest.mark.parametrize("cfg", [18, 19])
 def test_gemm256_full_chip_exact_integers(gpu, cfg):
-    """config 17 at the bench's size (30 streams: M = 21,600, fc1 shape, 1020 workgroups = 4 rounds
+    """configs 18 / 19 at the bench's size (30 streams: M = 21,600, fc1 shape, 1020 workgroups = 4 rounds
     on 256 CUs) with small-integer operands: every output must be the exact integer, three launches
     in a row. A half-tile read before its LDS-DMA landed, or overwritten while still being read,
     only shows under full-chip memory load - this is the case the small shapes cannot reach."""
@@ -145,9 +145,9 @@ def test_gemm256_full_chip_exact_integers(gpu, cfg):
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=cfg), bf16_round(np.maximum(ref, 0)))
 
 
-@pytest.mark.parametrize("cfg", [17, 18])
+@pytest.mark.parametrize("cfg", [18])
 def test_gemm256_long_k_repeatable(gpu, cfg):
-    """config 17 on the fc2 shape of 4 streams (48 K-tiles, 36 workgroups), five launches: the
+    """config 18 on the fc2 shape of 4 streams (48 K-tiles, 36 workgroups), five launches: the
     results must agree with float32 NumPy and be bit-identical from launch to launch (a race
     between the LDS-DMA ring and the fragment reads would show as run-to-run differences)"""
     rng = np.random.default_rng(17)
@@ -242,13 +242,13 @@ def test_attention(gpu, B, N, H, scale, mode):
 @pytest.mark.parametrize("B,N,H,scale", [(1, 80, 2, 1.0), (2, 320, 12, 1.0), (1, 720, 12, 1.0), (3, 96, 2, 1.0),
                                          (1, 16, 1, 3.0), (2, 1008, 4, 0.5), (5, 720, 12, 2.0),
                                          (3, 100, 2, 1.0), (2, 980, 16, 0.5), (1, 36, 1, 2.0)])
-@pytest.mark.parametrize("mode", [3, 6, 8, 9])
+@pytest.mark.parametrize("mode", [3])
 def test_attention_mode3(gpu, B, N, H, scale, mode):
     """mode 3: LDS-DMA ring, 64-key steps, Vt with the permuted key order (tokens % 4 == 0).
     Covers a single partial tile (16, 36), a tail of 16 and of 32 keys (80, 720 / 96), full tiles
     (320), more tiles than ring stages (1008), token counts that are not multiples of 16 (100, 980,
     36: the last 16-key group is partly padding) and a ragged last query block. Mode 3: unchecked
-    first pass + careful second pass on demand; 6: the careful pass alone."""
+    first pass + careful second pass on demand."""
     rng = np.random.default_rng(N + H)
     D = H * 64
     qb, q = _rand_bf16(gpu, rng, (B * N, D), scale * 0.35)
@@ -262,7 +262,7 @@ def test_attention_mode3(gpu, B, N, H, scale, mode):
     assert np.array_equal(got, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=mode))   # run-to-run identical
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_attention_late_maximum_rescale(gpu, mode):
     """scores that grow by far more than the lazy-max threshold / score window late in the key
     sequence: the reference must move and everything accumulated before be rescaled (mode 3: the
@@ -283,7 +283,7 @@ def test_attention_late_maximum_rescale(gpu, mode):
     assert err.max() < 0.03 * max(1.0, np.abs(ref).max()), err.max()
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("level", [-20.0, -50.0, -64.0, -150.0, 55.0, 90.0])
 def test_attention_uniformly_offset_scores(gpu, mode, level):
     """every score of every query sits near `level` (log2 units): inside the window the kernel uses
@@ -308,7 +308,7 @@ def test_attention_uniformly_offset_scores(gpu, mode, level):
     assert np.abs(got - ref).max() < 0.02 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 4, 6, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 6, 18, 19])
 @pytest.mark.parametrize("tokens", [112, 100])
 def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     """Vt as attention mode 3 reads it: inside every group of 16 tokens OF A STREAM the 4-token runs
@@ -330,7 +330,7 @@ def test_qkv_permuted_vt_layout(gpu, cfg, tokens):
     assert np.all(vt_[:, :, unused] == 0)      # padding positions stay zero
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_attention_exact_selector(gpu, mode):
     """One key dominates each query (score gap >> 1): output must equal that key's V row (exact in
     bf16) — checks the permuted k-order of the P·V product and the Vt layout with asymmetric data."""
@@ -528,7 +528,7 @@ def _row_terms(x, eps=1e-6):
     return np.stack([rstd, -mean * rstd], axis=1)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 18])
 @pytest.mark.parametrize("epi", [0, 1, 4])
 def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
     """the three epilogues that write the residual stream (0 plain, 1 += old pair, 4 += positional rows):
@@ -552,7 +552,7 @@ def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
     assert np.abs(rs[:, 1] - ref[:, 1]).max() < 2e-4 * np.abs(ref[:, 1]).max()
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 18])
 def test_x_epilogues_exact_integers(gpu, cfg):
     """small-integer operands: every sum is exact and fits the 16 significant bits of the pair, so the
     X-epilogues must return the exact integers (a mis-staged row, a swapped hi / lo or a wrong addend
@@ -570,7 +570,7 @@ def test_x_epilogues_exact_integers(gpu, cfg):
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=4, cfg=cfg), ref + c0)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 18, 19])
 @pytest.mark.parametrize("epi", [2, 3])
 def test_folded_layernorm_in_the_bf16_epilogues(gpu, cfg, epi):
     """y = rowstat[m][0] * acc + (rowstat[m][1] * colsum[n] + bias[n]) ahead of GELU / ReLU: integer
@@ -592,7 +592,7 @@ def test_folded_layernorm_in_the_bf16_epilogues(gpu, cfg, epi):
         assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 5, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [2, 3, 5, 18, 19])
 def test_folded_layernorm_in_the_qkv_epilogue(gpu, cfg):
     """the same row / column terms through the QKV epilogue: q (scaled), k row-major and V transposed
     (the V tiles read the row terms per register, not per lane)"""
@@ -615,8 +615,8 @@ def test_folded_layernorm_in_the_qkv_epilogue(gpu, cfg):
 def test_attention_second_pass_only_where_needed(gpu):
     """mode 3 decides per workgroup (one stream and head, 128 queries): a batch in which ONE head of ONE
     stream has scores far outside the unchecked pass's range, all others ordinary ones - every head must
-    come out right, the extreme one through the careful second pass, and identical to mode 6 (careful
-    pass alone) wherever nothing left the +-32 window"""
+    come out right (the extreme one only the careful second pass can get right: 2^score overflows float32
+    there), the calm ones as close to the float32 answer as a batch without the extreme head"""
     rng = np.random.default_rng(314)
     B, N, H = 2, 320, 3
     D = H * 64
@@ -628,14 +628,11 @@ def test_attention_second_pass_only_where_needed(gpu):
     vb, v = _rand_bf16(gpu, rng, (B * N, D))
     ref = _attn_ref(q, k, v, B, N, H)
     got3 = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=3)
-    got6 = gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=6)
     assert np.isfinite(got3).all()
     assert np.abs(got3 - ref).max() < 0.03 * max(1.0, np.abs(ref).max())
     calm = np.ones((B * N, D), bool)
     calm[N:, 64:128] = False
-    # mode 6 sums the probabilities on the matrix pipe, mode 3 on the vector ALU (float32, other order): the
-    # bf16 outputs may differ by one unit in the last place, not more
-    assert np.all(np.abs(got3[calm] - got6[calm]) <= np.abs(got6[calm]) * 2.0 ** -7 + 1e-6)
+    assert np.abs(got3[calm] - ref[calm]).max() < 0.02 * max(1.0, np.abs(ref[calm]).max())
     assert np.array_equal(got3, gpu.op_attention_bf16(qb, kb, vb, B, N, H, mode=3))      # run-to-run identical
 
 

@@ -93,6 +93,76 @@ def test_crop_buffer_tier_changes_no_value(gpu, weights_tiny, box):
     assert all(o == out[0] for o in out)
 
 
+def test_no_graph_capture_inside_an_update_when_a_target_grows_through_the_crop_tiers(gpu, weights_cfg3):
+    """every crop tier's pass is captured and instantiated when the engine is created: a live stream
+    (/root/reference/src/pipeline.rs:26-37: 60 fps) whose target grows through both tier boundaries (~130 / ~200 px at
+    search 384) replays three different graphs and captures none - the capture counter stays at its creation value and no
+    update near a crossing stalls (a capture + instantiate of 66 launches costs several update times)"""
+    import time
+    import torch
+    w, h = 1920, 1080
+    sc = gpu.synth.MovingSquare(w, h, 64, seed=2)
+    buf = torch.from_numpy(sc.frame_nv12(0)).cuda()
+    trk = gpu.VitTrack.new(weights_cfg3)
+    g = trk.as_group()
+    assert g.graph_captures() == 3                      # all three tiers, before the first frame
+    p = buf.data_ptr()
+    trk.init_nv12_device(p, p + w * h, w, h, w, w, gpu.BBox.new(900, 480, 100, 100))
+    sizes = [100] * 20 + list(range(100, 282, 2))       # warm, then grow through both boundaries
+    lat = []
+    for s in sizes:
+        g.set_state_box(0, [960 - s / 2, 540 - s / 2, s, s])
+        a = time.perf_counter()
+        trk.update_nv12_device(p, p + w * h, w, h, w, w)
+        lat.append(time.perf_counter() - a)
+    assert g.graph_captures() == 3, "a pass captured a graph on the hot path"
+    rep = g.read_tensor("graph_replays")
+    assert rep.sum() == len(sizes) and (rep > 0).all(), rep      # all three captured passes really ran
+    steady = np.array(lat[20:])
+    p50, p99 = np.median(steady), np.percentile(steady, 99)
+    print(f"tier crossing: replays per tier {rep.tolist()}, update p50 {p50 * 1e3:.3f} ms, p99 {p99 * 1e3:.3f} ms, max {steady.max() * 1e3:.3f} ms")
+    assert p99 <= 1.2 * p50, (p50, p99)
+    # a tuning change re-captures at once (inside set_tuning), never inside the next update
+    g.set_tuning("head_band", 1)
+    assert g.graph_captures() == 6
+    trk.update_nv12_device(p, p + w * h, w, h, w, w)
+    assert g.graph_captures() == 6
+    # a 30-stream engine: the same three captures at creation
+    g30 = gpu.Group(weights_cfg3, n_streams=30)
+    assert g30.graph_captures() == 3
+    # eager engines capture nothing
+    ge = gpu.Group(weights_cfg3, n_streams=1, use_graph=False)
+    assert ge.graph_captures() == 0
+
+
+@pytest.mark.parametrize("w,h,n", [(64, 48, 3), (1920, 1080, 5), (31, 17, 70), (66, 50, 2), (3840, 2160, 2)])
+def test_batched_converter_is_the_single_frame_converter_per_frame(gpu, oracle, w, h, n):
+    """vt_nv12_to_rgb8_batch_device: n frames in one launch per 64, every frame bit-exact with the reference's
+    converter (oracle restatement of /root/reference/src/nv12_convert.rs:46-169), odd sizes through the general
+    kernel, a short buffer -> that frame all zero (:48-50), a buffer that does not cover an odd frame's reads refused"""
+    import torch
+    rng = np.random.default_rng(w * h + n)
+    nbytes = (w * h + w * ((h + 1) // 2) + 2 + 255) // 256 * 256      # 16-B aligned frames: sizes with w % 16 == 0 take the wide kernel
+    host = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+    src = torch.from_numpy(host).cuda()
+    dst = torch.full((n, w * h * 3), 7, dtype=torch.uint8, device="cuda")
+    lens = [nbytes] * n
+    short = n // 2
+    lens[short] = w * h * 3 // 2 - 1                     # the reference returns a zero frame for this one
+    gpu.nv12_to_rgb8_batch_device([src[i].data_ptr() for i in range(n)], lens, w, h, [dst[i].data_ptr() for i in range(n)])
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    for i in range(n):
+        ref, st = oracle.nv12_to_rgb8(host[i][:lens[i]], w, h, 2)
+        assert st == (1 if i == short else 0)
+        assert np.array_equal(got[i].reshape(h, w, 3), ref), i
+    if (w & 1) or (h & 1):                               # odd frames read past w*h*3/2: a buffer that stops there is refused
+        lens[0] = w * h * 3 // 2
+        with pytest.raises(gpu.VtError) as e:
+            gpu.nv12_to_rgb8_batch_device([src[i].data_ptr() for i in range(n)], lens, w, h, [dst[i].data_ptr() for i in range(n)])
+        assert e.value.code == -7
+
+
 def test_patch_matrix_bit_exact_yuy2(gpu, oracle, weights_tiny):
     """the IR pipeline's capture format (src/pipeline_ir.rs:27-41), 640x512"""
     rng = np.random.default_rng(9)

@@ -70,6 +70,19 @@ def _blocks(body):
     return blocks
 
 
+def _sreg_range(tok):
+    """(first, last) SGPR index of an operand like `s4` / `s[4:5]`, None for anything else"""
+    m = re.fullmatch(r"s(\d+)", tok)
+    if m:
+        return int(m.group(1)), int(m.group(1))
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    return (int(m.group(1)), int(m.group(2))) if m else None
+
+
+def _overlap(a, b):
+    return a is not None and b is not None and a[0] <= b[1] and b[0] <= a[1]
+
+
 def _check_function(name, body):
     """forward data flow over the control-flow graph: which VGPRs hold the destination of an inline-asm
     load that no inline-asm `s_waitcnt vmcnt(0)` has retired yet; any instruction touching one is an error.
@@ -136,14 +149,18 @@ def _check_function(name, body):
                 fall = False
                 break
             # constant flags and what is derived from them
+            # a write that OVERLAPS a tracked pair forgets it: the pair itself, one half of it (s_mov_b32 s4), or a pair that
+            # shares a register with it (s[5:6]); a constant move then (re)establishes its own pair
+            dst = _sreg_range(toks[1]) if len(toks) > 1 else None
+            if dst:
+                for k in [k for k in flags if _overlap(_sreg_range(k), dst)]:
+                    del flags[k]
             m = re.fullmatch(r"s_mov_b64\s+(s\[\d+:\d+\]),\s*(0|-1)", line.strip())
             if m:
                 flags[m.group(1)] = m.group(2) == "-1"
             elif op == "s_and_b64" and len(toks) == 4 and toks[1] == "vcc" and toks[2] == "exec" and toks[3] in flags:
                 vcc_const = flags[toks[3]]
             else:
-                if len(toks) > 1 and toks[1] in flags:             # any other write to a tracked pair
-                    del flags[toks[1]]
                 if len(toks) > 1 and toks[1] == "vcc" or op.startswith("v_cmp") or "vcc" in toks[1:2]:
                     vcc_const = None
                 elif op.startswith("v_") and "vcc" in line and not op.startswith("v_cndmask"):
@@ -223,3 +240,16 @@ def test_the_checker_itself_on_synthetic_isa():
         "s_mov_b64 s[2:3], 0", "v_cmp_gt_i32_e64 s[2:3], 1, v3")
     with pytest.raises(AssertionError, match="touches"):
         _check_function("unknown", unknown)
+    # a write to ONE HALF of a tracked pair, or to a pair overlapping it, makes the flag unknown as well: the stale constant
+    # (-1: the wait is always executed) must not survive it and prune the path around the wait, which - with s[2:3] unknown -
+    # reaches the reuse of v18 with the load pending
+    for clobber in ("s_mov_b32 s4, s9", "s_mov_b32 s5, 0", "s_or_b64 s[4:5], s[4:5], s[10:11]", "s_mov_b64 s[5:6], 0",
+                    "s_and_saveexec_b64 s[4:5], vcc"):
+        half = flagged.replace("s_branch .LBB0_5", clobber + "\n\ts_branch .LBB0_5").replace(
+            "s_mov_b64 s[2:3], 0", "v_cmp_gt_i32_e64 s[2:3], 1, v3")
+        with pytest.raises(AssertionError, match="touches"):
+            _check_function("half", half)
+    # ... while a write to a DIFFERENT pair leaves it alone
+    other = flagged.replace("s_branch .LBB0_5", "s_mov_b32 s6, s9\n\ts_branch .LBB0_5").replace(
+        "s_mov_b64 s[2:3], 0", "v_cmp_gt_i32_e64 s[2:3], 1, v3")
+    assert _check_function("other", other) == 1
