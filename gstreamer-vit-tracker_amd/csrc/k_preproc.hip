@@ -82,9 +82,7 @@ __global__ __launch_bounds__(256) void nv12_to_rgb8_kernel(const uint8_t* __rest
 // (48 B of RGB per row): every access is a full dwordx4 and a wave touches 1 KiB of contiguous Y /
 // 3 KiB of contiguous RGB per row, against 4-B loads and 12-B stores in the general kernel (measured
 // there: 2.4 TB/s at 1080p, 3.8 TB/s at 4K of the ~6.3 TB/s a copy reaches). Same integer arithmetic.
-// g: index of the 16 x 2 block in the frame (bpr = w / 16 blocks per row pair). NT: the RGB stores bypass the
-// caches (a batch of frames is written once and read by somebody else).
-template <bool NT>
+// g: index of the 16 x 2 block in the frame (bpr = w / 16 blocks per row pair).
 __device__ __forceinline__ void nv12_rgb_block16x2(const uint8_t* __restrict__ nv12, int w, int h, uint8_t* __restrict__ rgb,
                                                    long g, int bpr) {
     const uint8_t* yp = nv12;
@@ -113,11 +111,7 @@ __device__ __forceinline__ void nv12_rgb_block16x2(const uint8_t* __restrict__ n
         }
         u32x4_t* dst = reinterpret_cast<u32x4_t*>(rgb + ((size_t)row * w + col0) * 3);
         const u32x4_t s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]}, s2 = {o[8], o[9], o[10], o[11]};
-        if (NT) {
-            __builtin_nontemporal_store(s0, dst); __builtin_nontemporal_store(s1, dst + 1); __builtin_nontemporal_store(s2, dst + 2);
-        } else {
-            dst[0] = s0; dst[1] = s1; dst[2] = s2;
-        }
+        dst[0] = s0; dst[1] = s1; dst[2] = s2;
     }
 }
 
@@ -127,43 +121,108 @@ __global__ __launch_bounds__(256) void nv12_to_rgb8_wide_kernel(const uint8_t* _
     const long total = (long)bpr * ((h + 1) >> 1);
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (long)gridDim.x * blockDim.x)
-        nv12_rgb_block16x2<false>(nv12, w, h, rgb, g, bpr);
+        nv12_rgb_block16x2(nv12, w, h, rgb, g, bpr);
 }
 
 // ---- n frames per launch (vt_nv12_to_rgb8_batch_device) ------------------------------------------------------------
 // A host that still wants RGB for all its cameras (the reference converts every frame, src/pipeline.rs:105) pays one
 // launch ramp per call, not per frame: a single 1080p conversion is a 3.9-us kernel bounded by that ramp (0.29 of the HBM
-// roof), a batch of 30 is one 280-MB stream. The frame table travels in the kernel arguments; in[i] == nullptr = the
-// reference's all-zero frame for a short buffer (src/nv12_convert.rs:48-50). Same per-pixel arithmetic (the functions above).
+// roof), a batch is one stream of bytes. The frame table travels in the kernel arguments; in[i] == nullptr = the
+// reference's all-zero frame for a short buffer (src/nv12_convert.rs:48-50). Same per-pixel arithmetic as above.
+//
+// WIDE (w % 16 == 0, 16-B aligned frames): the STORE side decides the rate (tools/nv12_batch_probe.hip, 30 / 60 x 1080p):
+//   three 16-B stores per lane and row at a 48-B lane stride - every store instruction touches a third of each line it
+//   covers - plain 4.0 TB/s, non-temporal 2.7 (partial lines written through); the same bytes handed over through 3 KB of
+//   LDS per wave so that every store instruction writes 1 KB of WHOLE contiguous lines: plain 4.6-5.0 TB/s, non-temporal
+//   6.2-6.5 TB/s = 0.77-0.81 of the 8 TB/s roof (an output written once and read by somebody else gains nothing from the
+//   L2, and whole lines need no read-modify-write on the way out). A wave's 64 blocks of 16 x 2 pixels: converted in
+//   registers, written to the wave's LDS at lane * 48 (conflict-free: 12-dword stride), read back as chunk k * 64 + lane
+//   and stored at THAT chunk's address (source lane = chunk / 3, piece = chunk % 3) - a wave may straddle a row pair
+//   or a frame, every chunk carries its own destination.
 template <bool WIDE>
 __global__ __launch_bounds__(256) void nv12_to_rgb8_batch_kernel(Nv12Batch bt, int n, int w, int h) {
-    const int per_row = WIDE ? (w >> 4) : ((w + 3) >> 2);
-    const long per_frame = (long)per_row * (WIDE ? ((h + 1) >> 1) : h);
-    const long total = per_frame * n;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-        const int f = (int)(g / per_frame);
-        const long gl = g - (long)f * per_frame;
-        const uint8_t* src = bt.in[f];
-        uint8_t* dst = bt.out[f];
-        if (src == nullptr) {                       // short buffer: zero frame
-            if (WIDE) {
-                const int rp = (int)(gl / per_row), col0 = (int)(gl % per_row) << 4;
-                const u32x4_t z = {0u, 0u, 0u, 0u};
-                for (int r2 = 0; r2 < 2 && 2 * rp + r2 < h; ++r2) {
-                    u32x4_t* o = reinterpret_cast<u32x4_t*>(dst + ((size_t)(2 * rp + r2) * w + col0) * 3);
-                    o[0] = z; o[1] = z; o[2] = z;
-                }
-            } else {
+    if constexpr (!WIDE) {
+        const int per_row = (w + 3) >> 2;
+        const long per_frame = (long)per_row * h, total = per_frame * n;
+        for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+            const int f = (int)(g / per_frame);
+            const long gl = g - (long)f * per_frame;
+            uint8_t* dst = bt.out[f];
+            if (bt.in[f] == nullptr) {                  // short buffer: zero frame
                 const int row = (int)(gl / per_row), col0 = (int)(gl % per_row) * 4;
                 for (int c = col0; c < min(col0 + 4, w); ++c) {
                     uint8_t* o = dst + ((size_t)row * w + c) * 3;
                     o[0] = 0; o[1] = 0; o[2] = 0;
                 }
+                continue;
             }
-            continue;
+            nv12_rgb_group4(bt.in[f], w, h, dst, gl, per_row);
         }
-        if (WIDE) nv12_rgb_block16x2<true>(src, w, h, dst, gl, per_row);
-        else nv12_rgb_group4(src, w, h, dst, gl, per_row);
+    } else {
+        __shared__ __attribute__((aligned(16))) char lds[4][3072];
+        const int bpr = w >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const long per_frame = (long)bpr * ((h + 1) >> 1), total = per_frame * n;
+        char* my = lds[wave];
+        for (long g0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); g0 < total; g0 += (long)gridDim.x * blockDim.x) {
+            // this lane's block (clamped past the end: converted, never stored)
+            const long gc = g0 + lane < total ? g0 + lane : total - 1;
+            const int f = (int)(gc / per_frame);
+            const long gl = gc - (long)f * per_frame;
+            const uint8_t* src = bt.in[f];
+            const int rp = (int)(gl / bpr), col0 = (int)(gl % bpr) << 4;
+            u32x4_t uv = {0u, 0u, 0u, 0u};
+            if (src) uv = *reinterpret_cast<const u32x4_t*>(src + (size_t)w * h + (size_t)rp * w + col0);
+            // destinations of the three chunks this lane stores (row 0 of the chunk's row pair; + w * 3 for row 1)
+            uint8_t* dst[3];
+            bool live[3], two_rows[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int c = k * 64 + lane, L = c / 3, j = c - 3 * L;
+                const long gs = g0 + L;
+                live[k] = gs < total;
+                const long gsc = live[k] ? gs : total - 1;
+                const int fs = (int)(gsc / per_frame);
+                const long gls = gsc - (long)fs * per_frame;
+                const int rps = (int)(gls / bpr), cs = (int)(gls % bpr) << 4;
+                dst[k] = bt.out[fs] + ((size_t)(2 * rps) * w + cs) * 3 + j * 16;
+                two_rows[k] = 2 * rps + 1 < h;           // odd height: the last pair has one row
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int row = min(2 * rp + r2, h - 1);
+                uint32_t o[12];
+                if (src) {
+                    const u32x4_t y4 = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * w + col0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {         // 4 pixels = one Y dword and one UV dword (2 pairs)
+                        int r[4], gg[4], b[4];
+                        const int u0 = uv[q] & 255, v0 = (uv[q] >> 8) & 255, u1 = (uv[q] >> 16) & 255, v1 = uv[q] >> 24;
+                        yuv_to_rgb(y4[q] & 255, u0, v0, r[0], gg[0], b[0]);
+                        yuv_to_rgb((y4[q] >> 8) & 255, u0, v0, r[1], gg[1], b[1]);
+                        yuv_to_rgb((y4[q] >> 16) & 255, u1, v1, r[2], gg[2], b[2]);
+                        yuv_to_rgb(y4[q] >> 24, u1, v1, r[3], gg[3], b[3]);
+                        o[3 * q + 0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+                        o[3 * q + 1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+                        o[3 * q + 2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+                    }
+                } else {                                  // short buffer: zero frame
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) o[e] = 0u;
+                }
+                u32x4_t* wl = reinterpret_cast<u32x4_t*>(my + lane * 48);
+                wl[0] = u32x4_t{o[0], o[1], o[2], o[3]};
+                wl[1] = u32x4_t{o[4], o[5], o[6], o[7]};
+                wl[2] = u32x4_t{o[8], o[9], o[10], o[11]};
+                __builtin_amdgcn_wave_barrier();          // wave-private LDS: program order + the compiler's lgkmcnt waits
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(my + (k * 64 + lane) * 16);
+                    if (live[k] && (r2 == 0 || two_rows[k]))
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(dst[k] + (size_t)r2 * w * 3));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
 }
 
@@ -178,7 +237,7 @@ hipError_t launch_nv12_to_rgb8_batch(const uint8_t* const* d_in, uint8_t* const*
         }
         const long per_frame = wide ? (long)(w >> 4) * ((h + 1) >> 1) : (long)((w + 3) >> 2) * h;
         const long total = per_frame * m;
-        int blocks = (int)std::min<long>((total + 255) / 256, 256 * 8);       // 8 blocks per CU, grid-stride the rest
+        int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);      // 16 blocks per CU, grid-stride the rest
         if (blocks < 1) blocks = 1;
         if (wide) vt_launch(nv12_to_rgb8_batch_kernel<true>, dim3(blocks), dim3(256), 0, st, bt, m, w, h);
         else vt_launch(nv12_to_rgb8_batch_kernel<false>, dim3(blocks), dim3(256), 0, st, bt, m, w, h);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
 #include "../include/vittrack_hip.h"
 
 typedef int (*fn_create)(const char*, int, const vt_config*, vt_tracker**);
@@ -61,6 +62,11 @@ static void* must_sym(void* lib, const char* name) {
         exit(2);
     }
     return p;
+}
+
+static int cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
 }
 
 int main(int argc, char** argv) {
@@ -166,16 +172,27 @@ int main(int argc, char** argv) {
         fprintf(stderr, "vt_init_nv12: %d %s\n", rc, last_error());
         return 1;
     }
+    double* lat = (double*)calloc((size_t)frames, sizeof(double));
     for (int t = 0; t < frames; ++t) {                              /* tracker.update(frame t) */
         const uint8_t* y = buf + (size_t)t * fbytes;
         vt_result r;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         rc = update_nv12(trk, y, y + (size_t)w * h, w, h, w, uvs, &r);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
         if (rc != VT_OK) {
             fprintf(stderr, "vt_update_nv12: %d %s\n", rc, last_error());
             return 1;
         }
+        if (lat) lat[t] = (double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3;
         printf("%d %d %.9g %d %d %d %d\n", t, r.success, r.score, r.bbox.x, r.bbox.y, r.bbox.width, r.bbox.height);
     }
+    if (lat && frames > 40) {       /* what a compiled host sees per update (stderr; the first 20 updates are warm-up) */
+        const int n = frames - 20;
+        qsort(lat + 20, (size_t)n, sizeof(double), cmp_double);
+        fprintf(stderr, "update latency from C, %d updates: p50 %.1f us  p99 %.1f us\n", n, lat[20 + n / 2], lat[20 + (n * 99) / 100]);
+    }
+    free(lat);
     destroy(trk);
     free(buf);
     dlclose(lib);

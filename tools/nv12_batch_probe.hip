@@ -4,7 +4,7 @@
 //      of each line it covers), non-temporal
 //   B  the same with plain stores
 //   C  a wave's 3 KB of a row go through 3 KB of LDS: every store instruction writes 1 KB of whole contiguous lines, plain
-//   D  C with non-temporal stores
+//   D  C with non-temporal stores   <- what k_preproc.hip ships (nv12_to_rgb8_batch_kernel<true>; results: profiles/r06_nv12_batch_probe.txt)
 // Every variant is checked against variant B byte for byte before it is timed.
 #include <cstdio>
 #include <cstdlib>
@@ -15,13 +15,47 @@ thread_local LaunchProbe* vt_launch_probe = nullptr;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+// the per-lane form of k_preproc.hip's nv12_rgb_block16x2 with the store flavour as a parameter
+template <bool NT>
+__device__ __forceinline__ void probe_block16x2(const uint8_t* __restrict__ nv12, int w, int h, uint8_t* __restrict__ rgb, long g, int bpr) {
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)w * h;
+    const int rp = (int)(g / bpr), col0 = (int)(g % bpr) << 4;
+    const uint4 uv = *reinterpret_cast<const uint4*>(uvp + (size_t)rp * w + col0);
+    const uint32_t uvw[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+        const int row = 2 * rp + r2;
+        if (row >= h) break;
+        const uint4 y4 = *reinterpret_cast<const uint4*>(yp + (size_t)row * w + col0);
+        const uint32_t yw[4] = {y4.x, y4.y, y4.z, y4.w};
+        uint32_t o[12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int r[4], gg[4], b[4];
+            const int u0 = uvw[q] & 255, v0 = (uvw[q] >> 8) & 255, u1 = (uvw[q] >> 16) & 255, v1 = uvw[q] >> 24;
+            yuv_to_rgb(yw[q] & 255, u0, v0, r[0], gg[0], b[0]);
+            yuv_to_rgb((yw[q] >> 8) & 255, u0, v0, r[1], gg[1], b[1]);
+            yuv_to_rgb((yw[q] >> 16) & 255, u1, v1, r[2], gg[2], b[2]);
+            yuv_to_rgb(yw[q] >> 24, u1, v1, r[3], gg[3], b[3]);
+            o[3 * q + 0] = r[0] | (gg[0] << 8) | (b[0] << 16) | (r[1] << 24);
+            o[3 * q + 1] = gg[1] | (b[1] << 8) | (r[2] << 16) | (gg[2] << 24);
+            o[3 * q + 2] = b[2] | (r[3] << 8) | (gg[3] << 16) | (b[3] << 24);
+        }
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(rgb + ((size_t)row * w + col0) * 3);
+        const u32x4_t s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]}, s2 = {o[8], o[9], o[10], o[11]};
+        if (NT) { __builtin_nontemporal_store(s0, dst); __builtin_nontemporal_store(s1, dst + 1); __builtin_nontemporal_store(s2, dst + 2); }
+        else { dst[0] = s0; dst[1] = s1; dst[2] = s2; }
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void probe_direct(Nv12Batch bt, int n, int w, int h) {
     const int bpr = w >> 4;
     const long per_frame = (long)bpr * ((h + 1) >> 1), total = per_frame * n;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
         const int f = (int)(g / per_frame);
-        nv12_rgb_block16x2<NT>(bt.in[f], w, h, bt.out[f], g - (long)f * per_frame, bpr);
+        probe_block16x2<NT>(bt.in[f], w, h, bt.out[f], g - (long)f * per_frame, bpr);
     }
 }
 

@@ -27,6 +27,7 @@ ap.add_argument("--family", default="")
 ap.add_argument("--streams", type=int, default=0)
 ap.add_argument("--algorithmic-bytes", type=float, default=0.0)
 ap.add_argument("--command", default="")
+ap.add_argument("--kernel-sha", default="", help="vt_build_info()'s k_gemm256 of the library the passes ran on (bench.py prints the traffic only for that build)")
 a = ap.parse_args()
 
 acc, cnt, dur = {}, {}, []
@@ -60,5 +61,7 @@ if dur:
 out["provenance"] = ("rocprofv3 --pmc passes (one counter group per run) of `" + (a.command or "tools/one_gemm.py") +
                      "` on MI355X, summarised by tools/pmc_summary.py; reads = 2 x FETCH_SIZE (gfx950 "
                      "correction, MI355X_MICROARCH.md section HBM), writes = WRITE_SIZE")
+if a.kernel_sha:
+    out["kernel_source_sha256"] = a.kernel_sha
 json.dump(out, open(a.out, "w"), indent=1)
 print(json.dumps(out, indent=1))
