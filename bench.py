@@ -681,9 +681,16 @@ def run_rank(args):
         for (cw, ch, nfr) in ((1920, 1080, 0), (3840, 2160, 0), (1920, 1080, 30), (1920, 1080, 60)):
             us = time_converter(cw, ch, nfr, 50 if nfr == 0 else 20)
             by = cw * ch * 4.5 * max(nfr, 1)                    # 1.5 B read + 3 B written per pixel
-            bk.append({"kernel": "nv12_to_rgb8_kernel" if nfr == 0 else "nv12_to_rgb8_batch_kernel",
-                       "frame": f"{cw}x{ch}" + (f" x {nfr} frames in one launch (vt_nv12_to_rgb8_batch_device)" if nfr else ""),
-                       "us": us, "algorithmic_bytes": by, "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS})
+            rec = {"kernel": "nv12_to_rgb8_kernel" if nfr == 0 else "nv12_to_rgb8_batch_kernel",
+                   "frame": f"{cw}x{ch}" + (f" x {nfr} frames in one launch (vt_nv12_to_rgb8_batch_device)" if nfr else ""),
+                   "us": us, "algorithmic_bytes": by, "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS}
+            if nfr == 30:       # HBM bytes of this shape from the committed PMC passes (separate rocprofv3 runs): 1.00 x algorithmic
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r06_nv12_batch_pmc.json")))
+                    rec["traffic"], rec["traffic_source"] = pm["traffic_bytes_per_launch"], pm["provenance"]
+                except Exception:
+                    rec["traffic"] = None
+            bk.append(rec)
         pre = [p for p in prof if p["name"] == "preproc_search"]
         if pre:
             crop_side = 4.0 * sq

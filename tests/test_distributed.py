@@ -136,6 +136,29 @@ def test_externally_launched_ranks_set_the_ipc_mode_themselves(vt, weights_tiny)
     _check_masks(d, 2)
 
 
+def test_eight_ranks_one_stream_each_is_the_literal_cfg4_line(vt, weights_tiny):
+    """BASELINE.json configs[3] taken literally - 8 independent streams, ONE per GPU, on 8 GPUs - as far as a CPU box can
+    rehearse it: `bench.py --gpus 8 --streams 1 --groups 1 --dry-run` self-launches eight gloo ranks; the line says
+    cfg4_literal, carries eight per-rank rates and a collective record of world size 8, the eight ranks hold disjoint global
+    stream ids and (where the box has at least eight CPUs) disjoint CPU masks"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "1",
+                        "--workload", "tiny", "--streams", "1", "--groups", "1", "--dry-run"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["collective"]["world_size"] == 8
+    assert d["collective"]["backend"] == "gloo" and d["collective"]["broadcast_bytes"] == os.path.getsize(weights_tiny)
+    assert d["config"]["cfg4_literal"] is True and d["config"]["cfg4_shape"] is True and d["config"]["streams_per_gpu"] == 1
+    # rank r "took" 0.5 + r/4 s for 1 stream x 6 steps: whole job = 48 frames / 2.25 s (the slowest rank)
+    assert len(d["per_rank_fps"]) == 8 and d["per_rank_fps"][0] == pytest.approx(12.0) and d["per_rank_fps"][7] == pytest.approx(6 / 2.25)
+    assert d["value"] == pytest.approx(48 / 2.25)
+    _check_masks(d, 8)
+
+
 def test_bench_launcher_does_not_touch_torch_in_the_parent_and_propagates_failure(vt):
     """the parent of a self-launch must not initialise the GPU (a HIP-initialised process may not be
     replaced or forked on this pool): bench.self_launch imports nothing heavy; a failing child
