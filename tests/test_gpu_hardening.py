@@ -136,3 +136,43 @@ def test_window_smaller_than_the_crop_reads_black_not_out_of_bounds(gpu, weights
         with pytest.raises(gpu.VtError) as e:
             g_win.update_device([bad])
         assert e.value.code == -1
+
+
+def test_a_map_the_head_band_kernel_cannot_plan_takes_the_gemm_head(gpu, tmp_path):
+    """advisor, round 5: the engine asked headconv_supported() only; for C = 128 and a map of ~84..112 cells per row the
+    band kernel's planner finds no band height (halo image + weight ring exceed the CU's 160 KiB of LDS even at one map
+    row), launch_headconv then refused every launch and EVERY pass failed with 'kernel launch failed'. Since round 6 the
+    planner is consulted for all three layer kinds when the engine is created and such a model runs its head as implicit
+    GEMMs + head_out + decode. A one-layer model with a 96 x 96 score map (search 1536, patch 16, C = 128): the pass runs,
+    results are finite and the same with the band kernel switched off by hand (it IS off)."""
+    w = gpu.weights
+    cfg = w.ModelConfig("wide_grid96_t512_s1536", 16, 512, 1536, 128, 1, head_ch=128)
+    assert cfg.grid_s == 96 and cfg.n_tokens == 10240
+    path = str(tmp_path / "grid96.vtw")
+    with open(path, "wb") as f:
+        f.write(w.pack_blob(cfg, w.generate_tensors(cfg, use_asset=False)))
+    W, H = 1920, 1080
+    sc = gpu.synth.MovingSquare(W, H, 200, seed=3)
+    out = []
+    for band in (None, 0):
+        trk = gpu.VitTrack.new(path)
+        if band is not None:
+            trk.as_group().set_tuning("head_band", band)
+        f0 = gpu.NV12Frame(sc.frame_nv12(0), W, H)
+        trk.init(f0, gpu.BBox.new(*sc.gt_box(0)))
+        r = [trk.update(gpu.NV12Frame(sc.frame_nv12(t), W, H)) for t in range(1, 4)]       # before the fix: VtError -5
+        assert all(np.isfinite(x.score) for x in r)
+        out.append([(x.success, x.score, tuple(x.bbox)) for x in r])
+        names = {p["name"] for p in trk.as_group().profile_device([_dev_frame(gpu, sc.frame_nv12(4), W, H)], iters=1)}
+        assert "decode" in names and not any(n.startswith("head_conv") for n in names), names     # the GEMM head ran
+    assert out[0] == out[1]
+
+
+_keep = []
+
+
+def _dev_frame(gpu, buf, w, h):
+    import torch
+    t = torch.from_numpy(buf).cuda()
+    _keep.append(t)
+    return gpu.frame_nv12(t.data_ptr(), t.data_ptr() + w * h, w, h)
