@@ -158,9 +158,12 @@ def pin_rank(local: int, world: int) -> dict:
     that nothing else is imported first)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_vt_placement", os.path.join(ROOT, "gstreamer-vit-tracker_amd", "placement.py"))
-    pl = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(pl)
-    return pl.apply(local, world)
+    try:            # placement is an optimisation: nothing it meets on a machine may stop the bench
+        pl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pl)
+        return pl.apply(local, world)
+    except Exception as e:
+        return {"cpus": "", "n": 0, "source": f"placement failed, mask left as given: {e!r}"}
 
 
 def run_rank(args):

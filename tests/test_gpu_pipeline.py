@@ -135,7 +135,8 @@ def test_no_graph_capture_inside_an_update_when_a_target_grows_through_the_crop_
     assert ge.graph_captures() == 0
 
 
-@pytest.mark.parametrize("w,h,n", [(64, 48, 3), (1920, 1080, 5), (31, 17, 70), (66, 50, 2), (3840, 2160, 2)])
+@pytest.mark.parametrize("w,h,n", [(64, 48, 3), (1920, 1080, 5), (31, 17, 70), (66, 50, 2), (3840, 2160, 2), (64, 49, 3), (48, 31, 130),
+                                   (1920, 1081, 2)])
 def test_batched_converter_is_the_single_frame_converter_per_frame(gpu, oracle, w, h, n):
     """vt_nv12_to_rgb8_batch_device: n frames in one launch per 64, every frame bit-exact with the reference's
     converter (oracle restatement of /root/reference/src/nv12_convert.rs:46-169), odd sizes through the general
