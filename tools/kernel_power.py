@@ -1,7 +1,7 @@
 """Socket power and shader clock while ONE kernel of the pass loops alone on the chip (rocm-smi sampled beside an
 operator-level timing loop): which kernels run AT the 1,400-W package limit (their time is energy), which below it
 (their time is structure), and the energy of one launch = power x time.
-   python tools/kernel_power.py [seconds per kernel]   (on the GPU box)"""
+   python tools/kernel_power.py [seconds per kernel] [name,name]   (on the GPU box; VITTRACK_HIP_LIB selects a tuning build)"""
 import re
 import subprocess
 import sys
@@ -12,6 +12,7 @@ sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]
 import gstreamer_vit_tracker_amd as vt
 
 SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None       # substrings of the kernel names to run
 B = 30
 M = 720 * B
 
@@ -56,4 +57,5 @@ kernels = [
 ]
 print(f"# one kernel looping alone, {SECS:.0f} s each, {B} streams (M = {M}); rocm-smi every 0.25 s, first quarter of the samples dropped")
 for k in kernels:
-    run(*k)
+    if ONLY is None or any(o in k[0] for o in ONLY):
+        run(*k)
