@@ -730,7 +730,7 @@ def overlay_rgb8(rgb: np.ndarray, cmds, device: int = 0) -> np.ndarray:
 
 def op_gemm_bf16(a_bits, w_bits, bias, c_init=None, epilogue=0, device=0, cfg=-1, rowstat=None,
                  colsum=None, want_rowstat=False, eps=1e-6):
-    """vt_op_gemm_bf16. epilogue 0 / 1 / 4: the X-epilogues (x comes back as the sum of the bf16 pair the
+    """vt_op_gemm_bf16. epilogue 0 / 1 / 4: the X-epilogues (x comes back as the value of the 3-byte pair the
     engine stores; want_rowstat: also the finalized (rstd, -mean * rstd) per row -> (x, rowstat));
     2 / 3: GELU / ReLU to bf16, with a folded LayerNorm if rowstat [M,2] and colsum [N] are given"""
     a_bits = np.ascontiguousarray(a_bits, np.uint16)
@@ -826,18 +826,19 @@ def op_headconv(t_bf16_bits, w_bf16_bits, bias, B, grid, conv3x3=True, R=0, ncb=
     return out
 
 
-def op_headconv_ln(xh_bits, xl_bits, gamma, beta, w_bf16_bits, bias, B, grid, ntok, off, fused=True, eps=1e-6, R=0, ncb=0,
+def op_headconv_ln(xh_bits, xl_lo8, gamma, beta, w_bf16_bits, bias, B, grid, ntok, off, fused=True, eps=1e-6, R=0, ncb=0,
                    device=0):
-    """vt_op_headconv_ln_bf16: relu(LayerNorm(xh + xl)[search rows] . w^T + bias) -> [B*grid*grid][N] float32; fused: one
-    launch (the band kernel normalises its rows itself), else the LayerNorm kernel followed by the band kernel"""
+    """vt_op_headconv_ln_bf16: relu(LayerNorm(xh + lo8 * 2^-12)[search rows] . w^T + bias) -> [B*grid*grid][N] float32 (the
+    residual pair of specification v3: bf16 bits + signed bytes); fused: one launch (the band kernel normalises its rows
+    itself), else the LayerNorm kernel followed by the band kernel"""
     xh = np.ascontiguousarray(xh_bits, np.uint16)
-    xl = np.ascontiguousarray(xl_bits, np.uint16)
+    xl = np.ascontiguousarray(xl_lo8, np.int8)
     w = np.ascontiguousarray(w_bf16_bits, np.uint16)
     D, N = xh.shape[1], w.shape[0]
     assert xh.shape == xl.shape == (B * ntok, D) and w.shape[1] == D
     out = np.empty((B * grid * grid, N), np.float32)
     u16 = POINTER(ctypes.c_uint16)
-    _check_op(ops_lib().vt_op_headconv_ln_bf16(device, xh.ctypes.data_as(u16), xl.ctypes.data_as(u16),
+    _check_op(ops_lib().vt_op_headconv_ln_bf16(device, xh.ctypes.data_as(u16), xl.ctypes.data_as(POINTER(ctypes.c_int8)),
                                         _f32(np.ascontiguousarray(gamma, np.float32)),
                                         _f32(np.ascontiguousarray(beta, np.float32)), c_float(eps), ntok, off,
                                         w.ctypes.data_as(u16), _f32(np.ascontiguousarray(bias, np.float32)), _f32(out),

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     if constexpr (EPI == EPI_F32_POS || EPI == EPI_RESID || EPI == EPI_F32) {
-        // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics ------------------------
+        // ---- X-epilogues: the residual stream as the 3-byte pair (bf16 + lo8, vt_common.hpp) + chunk statistics ----
         // The accumulators (row on the lane, 4 consecutive columns per register quad) are staged as a
         // float32 tile [BM][BN] in the dead operand ring (16-B chunk c of row r at c ^ (r & 7)) and written
         // out row-wise, 8 consecutive columns per lane: addend, bias, statistics of the 32-column chunk a
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
         // the registers are not touched until the vmcnt(0) below. Rows are clamped: every address is valid.
         constexpr bool EARLY = TM * TN == 1 && EPI != EPI_F32;
         u32x4_t e_a[PIECES][2], e_bias[2];
+        u32x2_t e_l[PIECES] = {};          // EPI_RESID: the addend's lo8 bytes (e_a[k][1] is not used then)
         if constexpr (EARLY) {
             e_bias[0] = gload_b128_asm(p.bias + n8);
             e_bias[1] = gload_b128_asm(p.bias + n8 + 4);
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
                     e_a[k][1] = gload_b128_asm(src + 4);
                 } else {
                     e_a[k][0] = gload_b128_asm(p.Xh + (size_t)mc * p.ldx + n8);
-                    e_a[k][1] = gload_b128_asm(p.Xl + (size_t)mc * p.ldx + n8);
+                    e_l[k] = gload_b64_asm(p.Xl + (size_t)mc * p.ldx + n8);
                 }
             }
         }
@@ -464,7 +465,13 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
         float bias8[8];
         if constexpr (EARLY) {
             vm_drain();
-            if constexpr (PIECES == 2)
+            if constexpr (EPI == EPI_RESID) {          // hi (16 B) + lo8 (8 B) per piece
+                if constexpr (PIECES == 2)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_l[0]),
+                                 "+v"(e_a[1][0]), "+v"(e_l[1]) : : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_l[0]) : : "memory");
+            } else if constexpr (PIECES == 2)
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_a[0][0]), "+v"(e_a[0][1]),
                              "+v"(e_a[1][0]), "+v"(e_a[1][1]) : : "memory");
             else
@@ -499,11 +506,12 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
 #pragma unroll
                 for (int e = 0; e < 8; ++e) add[e] = __uint_as_float(u[e]);
             } else {
-                u32x4_t hi, lo;
-                if constexpr (EARLY) { hi = e_a[k][0]; lo = e_a[k][1]; }
+                u32x4_t hi;
+                u32x2_t lo;
+                if constexpr (EARLY) { hi = e_a[k][0]; lo = e_l[k]; }
                 else {
                     hi = *reinterpret_cast<const u32x4_t*>(p.Xh + (size_t)mc * p.ldx + n8);
-                    lo = *reinterpret_cast<const u32x4_t*>(p.Xl + (size_t)mc * p.ldx + n8);
+                    lo = *reinterpret_cast<const u32x2_t*>(p.Xl + (size_t)mc * p.ldx + n8);
                 }
                 x_join8(hi, lo, add);
             }
@@ -515,11 +523,12 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
             }
             float csum, cm2;
             x_chunk_stats(x, csum, cm2);
-            u32x4_t hi, lo;
+            u32x4_t hi;
+            u32x2_t lo;
             x_split8(x, hi, lo);
             if (m < p.M) {
                 *reinterpret_cast<u32x4_t*>(p.Xh + (size_t)m * p.ldx + n8) = hi;
-                *reinterpret_cast<u32x4_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
+                *reinterpret_cast<u32x2_t*>(p.Xl + (size_t)m * p.ldx + n8) = lo;
                 if (p.cstat && (ch8 & 3) == 0)
                     p.cstat[(size_t)m * nchunk + (n8 / VT_STAT_CHUNK)] = make_float2(csum, cm2);
             }

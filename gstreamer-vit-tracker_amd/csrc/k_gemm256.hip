@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const unsigned long long xs_t1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        // ---- X-epilogues: the residual stream as a bf16 pair + chunk statistics (vt_common.hpp) ----------
+        // ---- X-epilogues: the residual stream as the 3-byte pair (bf16 + lo8) + chunk statistics (vt_common.hpp) ----
         // Two passes (i = 0, 1) of 128 rows x 256 f32 staged in LDS: row lr = wr*64 + mf*16 + l15 of the
         // pass, 16-B chunk ch of the row stored at ch ^ (lr & 7). Written out row-wise, 8 consecutive
         // columns per lane (two rows per wave instruction: 512 B of hi and 512 B of lo per row): addend,
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const size_t ro = (size_t)mc * p.ldx * 2;
                 const uint32_t lo_ = (mc + 1 < p.M) ? lane_off : lane_off0;
                 a0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xh) + ro + lo_);
-                a1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.Xl) + ro + lo_);
+                // the lo8 plane: one byte per element, the same (row, column) at half the byte offset: 8 B per lane
+                const u32x2_t l8 = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(p.Xl) + (ro >> 1) + (lo_ >> 1));
+                a1 = u32x4_t{l8[0], l8[1], 0u, 0u};
             } else if constexpr (EPI == EPI_F32_POS) {
                 const int m = out_row(i, it);
                 const int mc = m < p.M ? m : p.M - 1;     // clamped: every address valid, value unused
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const f32x4_t f1 = *reinterpret_cast<const f32x4_t*>(smem + lr * 1024 + (((2 * c8 + 1) ^ (lr & 7)) << 4));
                 float add[8], x[8];
                 if constexpr (EPI == EPI_RESID) {
-                    x_join8(ad[it][0], ad[it][1], add);
+                    x_join8(ad[it][0], u32x2_t{ad[it][1][0], ad[it][1][1]}, add);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { add[e] = __uint_as_float(ad[it][0][e]); add[4 + e] = __uint_as_float(ad[it][1][e]); }
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
                 float csum, cm2;
                 x_chunk_stats(x, csum, cm2);
-                u32x4_t hi, lo;
+                u32x4_t hi;
+                u32x2_t lo;
                 x_split8(x, hi, lo);
                 // chunk partials: two chunks (this quad's and the next one's) per 16-B WRITE-THROUGH (sc1) store -
                 // the row panel's last workgroup may read them in this launch (finalize below); as 8-B sc1 stores
@@ -365,16 +368,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const int mu = row_u(i, it);
                 const size_t ro = (size_t)mu * p.ldx * 2;
                 char* const dh = reinterpret_cast<char*>(p.Xh) + ro + lane_off;
-                char* const dl = reinterpret_cast<char*>(p.Xl) + ro + lane_off;
+                char* const dl = reinterpret_cast<char*>(p.Xl) + (ro >> 1) + (lane_off >> 1);      // lo8 plane: 8 B per lane
                 char* const dc = reinterpret_cast<char*>(p.cstat) + (size_t)mu * nchunk * 8 + lane_off_c;
                 const bool cst = p.cstat && (c8 & 7) == 0;
                 if (mu + 1 < p.M) {                 // scalar: both rows of the pair inside M
                     *reinterpret_cast<u32x4_t*>(dh) = hi;
-                    *reinterpret_cast<u32x4_t*>(dl) = lo;
+                    *reinterpret_cast<u32x2_t*>(dl) = lo;
                     if (cst) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dc), "v"(v4) : "memory");
                 } else if (mu + rsub < p.M) {       // the last row of an odd M
                     *reinterpret_cast<u32x4_t*>(dh) = hi;
-                    *reinterpret_cast<u32x4_t*>(dl) = lo;
+                    *reinterpret_cast<u32x2_t*>(dl) = lo;
                     if (cst) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dc), "v"(v4) : "memory");
                 }
             }

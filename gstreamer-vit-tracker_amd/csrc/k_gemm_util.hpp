@@ -84,6 +84,12 @@ __device__ __forceinline__ u32x4_t gload_b128_asm(const void* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// the same for 8 bytes (a lane's eight lo8 bytes of the residual pair)
+__device__ __forceinline__ u32x2_t gload_b64_asm(const void* p) {
+    u32x2_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 // sum over the four lanes of a quad (lanes 4k .. 4k+3), every lane gets the same bits: two DPP
 // quad_perm moves, no LDS traffic
@@ -96,7 +102,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 // ---- the X-epilogues' row-wise write-out: 8 consecutive columns of one row per lane ---------------
 // x[0..7]: the float32 residual values. Emits the chunk partials of the 32-column chunk the lane's quad
 // covers (quad-uniform: the four lanes of a quad hold the four 8-column groups of one chunk of one row),
-// and the bf16 pair. Fixed summation order -> run-to-run identical.
+// and the 3-byte pair. Fixed summation order -> run-to-run identical.
 __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, float& m2) {
     float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     s = quad_sum(s);
@@ -107,25 +113,7 @@ __device__ __forceinline__ void x_chunk_stats(const float (&x)[8], float& sum, f
     sum = s;
     m2 = quad_sum(q);
 }
-__device__ __forceinline__ void x_split8(const float (&x)[8], u32x4_t& hi, u32x4_t& lo) {
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
-        l[e] = pack_bf16x2(x[2 * e] - __uint_as_float(h[e] << 16), x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
-    }
-    hi = u32x4_t{h[0], h[1], h[2], h[3]};
-    lo = u32x4_t{l[0], l[1], l[2], l[3]};
-}
-// hi + lo of 8 columns as float32
-__device__ __forceinline__ void x_join8(const u32x4_t& hi, const u32x4_t& lo, float (&x)[8]) {
-    const uint32_t h[4] = {hi[0], hi[1], hi[2], hi[3]}, l[4] = {lo[0], lo[1], lo[2], lo[3]};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        x[2 * e] = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-        x[2 * e + 1] = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
-    }
-}
+// x_split8 / x_join8: the 3-byte residual pair, vt_common.hpp (shared with the LayerNorm readers)
 
 // value of the same lane of the other wave half (lane ^ 32): v_permlane32_swap, no LDS round trip
 __device__ __forceinline__ float other_half_f32(float v) {

@@ -350,12 +350,13 @@ __global__ __launch_bounds__(512) void head_conv_kernel(HeadConvArgs p, DecodeAr
             const int l32 = lane & 31, hwv = tid >> 5;
             const int D = p.K;
             const size_t tok0 = (size_t)b * p.in_stride + p.in_off + y0 * grid;
-            u32x4_t rh[3][LNC], rl[3][LNC];
+            u32x4_t rh[3][LNC];
+            u32x2_t rl[3][LNC];            // the row's lo8 bytes (3-byte residual pair, vt_common.hpp)
             auto fetch = [&](int it, int slot) {
                 int r = it * 16 + hwv;
                 r = r < cells ? r : cells - 1;
                 const u32x4_t* hr = reinterpret_cast<const u32x4_t*>(p.xh + (tok0 + r) * D);
-                const u32x4_t* lr = reinterpret_cast<const u32x4_t*>(p.xl + (tok0 + r) * D);
+                const u32x2_t* lr = reinterpret_cast<const u32x2_t*>(p.xl + (tok0 + r) * D);
 #pragma unroll
                 for (int j = 0; j < LNC; ++j) { rh[slot][j] = hr[l32 + 32 * j]; rl[slot][j] = lr[l32 + 32 * j]; }
             };

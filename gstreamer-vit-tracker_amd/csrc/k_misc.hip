@@ -2,14 +2,14 @@
 #include "vt_common.hpp"
 
 // ---- LayerNorm: one wave per row, row kept in registers, two-pass variance -----------------------
-// Residual stream in (float32, or SPLIT: the bf16 pair xh + xl of the engine, x = xh + xl), bf16 GEMM
+// Residual stream in (float32, or SPLIT: the 3-byte pair of the engine, x = xh + xl * 2^-12: vt_common.hpp), bf16 GEMM
 // operand out. In the engine only the FINAL LayerNorm (search tokens, before the head) runs as a kernel:
 // the two LayerNorms of every block are folded into the GEMMs that consume them (vt_common.hpp).
 // NCH = D / 128 float2 chunks per lane.
 template <int NCH, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const bf16_t* __restrict__ xh,
-                                                        const bf16_t* __restrict__ xl,
+                                                        const uint8_t* __restrict__ xl,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         bf16_t* __restrict__ y, int rows, int D,
@@ -23,12 +23,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float sum = 0.0f;
     if constexpr (SPLIT) {
         const uint32_t* hr = reinterpret_cast<const uint32_t*>(xh + in_row * D);
-        const uint32_t* lr = reinterpret_cast<const uint32_t*>(xl + in_row * D);
+        const uint16_t* lr = reinterpret_cast<const uint16_t*>(xl + in_row * D);      // two lo8 bytes per lane
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const uint32_t h = hr[lane + 64 * j], l = lr[lane + 64 * j];
-            v[j].x = __uint_as_float(h << 16) + __uint_as_float(l << 16);
-            v[j].y = __uint_as_float(h & 0xffff0000u) + __uint_as_float(l & 0xffff0000u);
+            v[j].x = __builtin_fmaf(lo8_f32(l, 0), VT_LO_Q, __uint_as_float(h << 16));
+            v[j].y = __builtin_fmaf(lo8_f32(l, 1), VT_LO_Q, __uint_as_float(h & 0xffff0000u));
         }
     } else {
         const float2* xr = reinterpret_cast<const float2*>(x + in_row * D);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NCH, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __restrict__ x,
                                                              const bf16_t* __restrict__ xh,
-                                                             const bf16_t* __restrict__ xl,
+                                                             const uint8_t* __restrict__ xl,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              bf16_t* __restrict__ y, int rows, int D,
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
     f32x4_t v[NCH][2];
     if constexpr (SPLIT) {
         const u32x4_t* hr = reinterpret_cast<const u32x4_t*>(xh + in_row * D);
-        const u32x4_t* lr = reinterpret_cast<const u32x4_t*>(xl + in_row * D);
+        const u32x2_t* lr = reinterpret_cast<const u32x2_t*>(xl + in_row * D);
 #pragma unroll
         for (int j = 0; j < NCH; ++j) ln_unpack_split(hr[l32 + 32 * j], lr[l32 + 32 * j], v[j]);
     } else {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* __rest
 }
 
 template <bool SPLIT>
-static hipError_t launch_layernorm_any(const float* x, const bf16_t* xh, const bf16_t* xl, const float* gamma,
+static hipError_t launch_layernorm_any(const float* x, const bf16_t* xh, const uint8_t* xl, const float* gamma,
                                        const float* beta, bf16_t* y, int rows, int D, int group, int in_stride,
                                        int in_off, float eps, hipStream_t st) {
     if (rows <= 0 || D % 128 != 0) return hipErrorInvalidValue;
@@ -145,7 +145,7 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
     return launch_layernorm_any<false>(x, nullptr, nullptr, gamma, beta, y, rows, D, group, in_stride, in_off, eps, st);
 }
 
-hipError_t launch_layernorm_split(const bf16_t* xh, const bf16_t* xl, const float* gamma, const float* beta,
+hipError_t launch_layernorm_split(const bf16_t* xh, const uint8_t* xl, const float* gamma, const float* beta,
                                   bf16_t* y, int rows, int D, int group, int in_stride, int in_off,
                                   float eps, hipStream_t st) {
     return launch_layernorm_any<true>(nullptr, xh, xl, gamma, beta, y, rows, D, group, in_stride, in_off, eps, st);

@@ -273,7 +273,7 @@ int vt_group_enable_taps(vt_group* g, int enable) try {
     DEVICE_SCOPE(e->device);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (enable && !e->d_taps)      // per slot: the hi and the lo half of the residual stream
-        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * 2 * e->B * e->d.ntok * e->d.D, e->stream));
+        HIPCHK(dalloc0(&e->d_taps, (size_t)(e->d.L + 1) * e->tap_slot_bytes(), e->stream));
     e->taps = enable != 0;
     return VT_OK;
 } VT_NOTHROW_INT
@@ -367,19 +367,21 @@ static int64_t copy_out_f32(const float* dsrc, int64_t count, float* out, int64_
         return set_err(VT_ERR_HIP, "read_tensor: copy failed");
     return count;
 }
-// the residual stream: hi + lo in float32 (the value the bf16 pair stands for)
-static int64_t copy_out_pair(const bf16_t* dhi, const bf16_t* dlo, int64_t count, float* out, int64_t cap) {
+// the residual stream in float32: the value the 3-byte pair stands for
+// (the 3-byte pair of specification v3: hi bf16 + lo8 * 2^-12)
+static int64_t copy_out_pair(const bf16_t* dhi, const uint8_t* dlo, int64_t count, float* out, int64_t cap) {
     if (!out) return count;
     if (cap < count) return set_err(VT_ERR_INVALID_ARG, "read_tensor: capacity %lld < %lld", (long long)cap, (long long)count);
-    std::vector<bf16_t> hi((size_t)count), lo((size_t)count);
+    std::vector<bf16_t> hi((size_t)count);
+    std::vector<int8_t> lo((size_t)count);
     if (hipMemcpy(hi.data(), dhi, 2 * count, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(lo.data(), dlo, 2 * count, hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(lo.data(), dlo, count, hipMemcpyDeviceToHost) != hipSuccess)
         return set_err(VT_ERR_HIP, "read_tensor: copy failed");
     for (int64_t i = 0; i < count; ++i) {
-        const uint32_t uh = ((uint32_t)hi[i]) << 16, ul = ((uint32_t)lo[i]) << 16;
-        float fh, fl;
-        memcpy(&fh, &uh, 4); memcpy(&fl, &ul, 4);
-        out[i] = fh + fl;
+        const uint32_t uh = ((uint32_t)hi[i]) << 16;
+        float fh;
+        memcpy(&fh, &uh, 4);
+        out[i] = fh + (float)lo[i] * VT_LO_Q;
     }
     return count;
 }
@@ -433,8 +435,10 @@ int64_t vt_group_read_tensor(vt_group* g, int stream, const char* name, float* o
     if (slot >= 0 && slot <= d.L) {
         if (!e->d_taps) return set_err(VT_ERR_INVALID_ARG, "taps not enabled (vt_group_enable_taps)");
         const size_t M = (size_t)e->B * d.ntok;
-        const bf16_t* hi = e->d_taps + ((size_t)slot * 2 * M + b * d.ntok) * d.D;
-        return copy_out_pair(hi, hi + M * d.D, (int64_t)d.ntok * d.D, out, capacity);
+        const uint8_t* base = e->d_taps + (size_t)slot * e->tap_slot_bytes();
+        const bf16_t* hi = reinterpret_cast<const bf16_t*>(base) + b * d.ntok * d.D;
+        const uint8_t* lo = base + sizeof(bf16_t) * M * d.D + b * d.ntok * d.D;
+        return copy_out_pair(hi, lo, (int64_t)d.ntok * d.D, out, capacity);
     }
     return set_err(VT_ERR_INVALID_ARG, "unknown tensor '%s'", name);
 } VT_NOTHROW_INT

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 // one device-resident input frame (mirrors vt_frame, 64-bit pointers)
 struct FrameDesc {
@@ -57,6 +58,19 @@ struct ModelDims {
 // (the attention kernels use v_exp_f32 = 2^x directly); float(log2 e) / 8 is exact in float32
 #define ATT_Q_SCALE (0.125f * 1.4426950408889634f)
 
+// NUMERICAL SPECIFICATION v3 (round 6). The residual stream x is stored as a 3-BYTE pair: Xh = bf16(x) [M][ldx] and
+// Xl = lo8 [M][ldx] bytes, lo8 = clamp(rint((x - Xh) * 2^12), -127, 127) as a signed integer: x = Xh + lo8 * 2^-12.
+// Until round 5 the low half was a second bf16 (4 bytes per element, 17 significant bits); the byte plane moves a
+// quarter less through the X-epilogues' read-modify-write and the final LayerNorm, the phases of the pass that are
+// bound by memory requests (profiles/r06_lo8_residual.txt: whole frame + 3 %). x - Xh is exact (Xh is x rounded to 8
+// significant bits), the scaling is a power of two, rint is round-to-nearest-even, Xh + lo8 * 2^-12 is exact in
+// float32: oracle (oracle/vit_ref.py split_residual) and kernels can differ only through the x they start from.
+// |x - Xh| <= 127 * 2^-12 holds for |x| < 16 (this model: |x| < 3.5); beyond it the clamp leaves part of the low half
+// behind - the value degrades towards plain bf16, it never wraps.
+#define VT_LO_SHIFT 12
+#define VT_LO_Q (1.0f / 4096.0f)
+#define VT_LO_MAX (127.0f / 4096.0f)
+// (comment of the v2 form, for the history of the format:)
 // The residual stream x is stored as a PAIR of bf16 matrices: Xh = bf16(x), Xl = bf16(x - Xh) (17
 // significant bits; Xh alone is the A operand of the GEMM that consumes the following LayerNorm). The
 // three epilogues that produce x (X-epilogues) also emit, per row and per 32-column chunk, the partial
@@ -80,7 +94,7 @@ struct GemmArgs {
     const bf16_t* W; int ldw;     // [N][K] row-major bf16 (one output feature per row)
     const float* bias;            // [N]
     int M, N, K;
-    bf16_t* Xh; bf16_t* Xl; int ldx;   // X-epilogues: the residual stream pair [M][ldx] (EPI_RESID: read, then written)
+    bf16_t* Xh; uint8_t* Xl; int ldx;  // X-epilogues: the residual stream pair [M][ldx] - bf16 high halves, lo8 bytes (EPI_RESID: read, then written)
     float2* cstat;                // X-epilogues: [M][N / 32] chunk partials (sum, M2), or null
     // X-epilogues of the 256x256 kernel (launch_gemm reports whether it was used): the last workgroup of
     // every 256-row panel finalizes the panel's row terms itself (no launch_rowstat_finalize needed)
@@ -132,8 +146,8 @@ int gemm_effective_config(const GemmArgs& a, int epilogue);
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y,
                             int rows, int D, int group, int in_stride, int in_off, float eps,
                             hipStream_t st);
-// the same on the split residual stream: x = xh + xl
-hipError_t launch_layernorm_split(const bf16_t* xh, const bf16_t* xl, const float* gamma, const float* beta,
+// the same on the split residual stream: x = xh + xl * 2^-12 (3-byte pair)
+hipError_t launch_layernorm_split(const bf16_t* xh, const uint8_t* xl, const float* gamma, const float* beta,
                                   bf16_t* y, int rows, int D, int group, int in_stride, int in_off,
                                   float eps, hipStream_t st);
 // rowstat[m] = (rstd, -mean * rstd) from the chunk partials of an X-epilogue (D = 32 * nchunk columns)
@@ -220,7 +234,8 @@ struct HeadConvArgs {
     unsigned long long* dbg;    // diagnostic builds only (VT_STAMPS): per-wave cycle sums [wgs][8][4]
     // 1x1 layer with the final LayerNorm inside (xh != nullptr; `in` is ignored): the layer's input row (b, cell) is
     // LayerNorm(xh + xl)[b * in_stride + in_off + cell][0..K) with gamma ln_g, beta ln_b
-    const bf16_t *xh, *xl;
+    const bf16_t* xh;
+    const uint8_t* xl;
     const float *ln_g, *ln_b;
     float ln_eps;
     int in_stride, in_off;
@@ -320,15 +335,51 @@ __device__ __forceinline__ void ln_load_coef(const float* gamma, const float* be
         asm volatile("" : "+v"(k.g[j][0]), "+v"(k.g[j][1]), "+v"(k.b[j][0]), "+v"(k.b[j][1]) : : "memory");
 }
 
-// x = hi + lo of the split residual stream: 8 values of a chunk from the two 16-B pieces
-__device__ __forceinline__ void ln_unpack_split(const u32x4_t h, const u32x4_t l, f32x4_t (&v)[2]) {
+// ---- the 3-byte residual pair (specification v3, top of this file) -------------------------------------------------
+// decode: element k of a lane's 8 consecutive columns = bf16 half k of h (16 B) + signed byte k of l (8 B) * 2^-12
+__device__ __forceinline__ float lo8_f32(uint32_t w, int byte) {
+    return (float)((int)(w << (24 - 8 * byte)) >> 24);          // sign-extended byte (v_bfe_i32 / SDWA sext) -> float
+}
+__device__ __forceinline__ void x_join8(const u32x4_t& hi, const u32x2_t& lo, float (&x)[8]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float even = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-        const float odd = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
-        v[e >> 1][(e & 1) * 2] = even;
-        v[e >> 1][(e & 1) * 2 + 1] = odd;
+        const uint32_t lw = lo[e >> 1];
+        x[2 * e] = __builtin_fmaf(lo8_f32(lw, (2 * e) & 3), VT_LO_Q, __uint_as_float(hi[e] << 16));
+        x[2 * e + 1] = __builtin_fmaf(lo8_f32(lw, (2 * e + 1) & 3), VT_LO_Q, __uint_as_float(hi[e] & 0xffff0000u));
     }
+}
+// encode: hi = bf16(x) (round to nearest even); d = x - hi (exact); lo8 = rint(clamp(d, +-127 q) / q) by the float add of
+// 1.5 * 2^11: the sum's ulp is q = 2^-12, the add rounds to nearest even, and the low byte of the sum's bit pattern
+// (0x45400000 + n) is the two's-complement lo8. The add is issued in its SDWA form with dst_sel:BYTE_k, which writes that
+// low byte straight into byte k of the destination dword - no extraction, no packing: 2 vector operations per element
+// (v_med3_f32 + v_add_f32_sdwa) where clamp + add + v_perm gathering took 2.75 (same-box A/B in profiles/r06_lo8_residual.txt:
+// + 0.5 % of the whole frame; without the clamp another + 0.2 %, not taken: a value beyond the range must saturate, not wrap).
+__device__ __forceinline__ void x_split8(const float (&x)[8], u32x4_t& hi, u32x2_t& lo) {
+    uint32_t h[4];
+    float c[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+        c[2 * e] = __builtin_amdgcn_fmed3f(x[2 * e] - __uint_as_float(h[e] << 16), -VT_LO_MAX, VT_LO_MAX);
+        c[2 * e + 1] = __builtin_amdgcn_fmed3f(x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u), -VT_LO_MAX, VT_LO_MAX);
+    }
+    hi = u32x4_t{h[0], h[1], h[2], h[3]};
+    const float magic = 3072.0f;            // SDWA takes no literal: a register
+    uint32_t w0, w1;
+#define VT_LO8_BYTE(W, K, UNUSED, C) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_" #K " dst_unused:" #UNUSED " src0_sel:DWORD src1_sel:DWORD" : W : "v"(C), "v"(magic))
+    VT_LO8_BYTE("=v"(w0), 0, UNUSED_PAD, c[0]); VT_LO8_BYTE("+v"(w0), 1, UNUSED_PRESERVE, c[1]);
+    VT_LO8_BYTE("+v"(w0), 2, UNUSED_PRESERVE, c[2]); VT_LO8_BYTE("+v"(w0), 3, UNUSED_PRESERVE, c[3]);
+    VT_LO8_BYTE("=v"(w1), 0, UNUSED_PAD, c[4]); VT_LO8_BYTE("+v"(w1), 1, UNUSED_PRESERVE, c[5]);
+    VT_LO8_BYTE("+v"(w1), 2, UNUSED_PRESERVE, c[6]); VT_LO8_BYTE("+v"(w1), 3, UNUSED_PRESERVE, c[7]);
+#undef VT_LO8_BYTE
+    lo = u32x2_t{w0, w1};
+}
+// the LayerNorm readers' form: 8 values of a chunk as two float4
+__device__ __forceinline__ void ln_unpack_split(const u32x4_t h, const u32x2_t l, f32x4_t (&v)[2]) {
+    float x[8];
+    x_join8(h, l, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = x[e];
 }
 
 // v: the row's values of this lane (overwritten); o[j]: the normalised chunk l32 + 32 j as 8 bf16

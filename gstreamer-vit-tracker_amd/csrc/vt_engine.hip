@@ -213,8 +213,8 @@ int Engine::load_blob_device(const void* d_src, size_t bytes) {
 size_t Engine::activation_bytes() const {
     const size_t M = (size_t)B * d.ntok, Ms = (size_t)B * d.ns;
     const size_t fold_rows = (size_t)d.L * (3 * d.D + d.mlp);      // folded QKV + fc1 weights of every layer
-    return 2 * (M * d.kpad + 2 * M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
-                Ms * d.D + 2 * Ms * d.C + fold_rows * d.D) +
+    return 2 * (M * d.kpad + M * d.D + M * 2 * d.D + (size_t)B * d.H * 64 * d.npad + M * d.D + M * d.mlp +
+                Ms * d.D + 2 * Ms * d.C + fold_rows * d.D) + M * d.D /* lo8 plane */ +
            8 * (M * (d.D / VT_STAT_CHUNK) + M) + 4 * (Ms * 8 + 2 * fold_rows) +
            (size_t)B * (sizeof(StreamState) + sizeof(FrameDesc) + sizeof(vt_result));
 }
@@ -234,7 +234,7 @@ int Engine::alloc_buffers() {
     }
     HIPCHK(dalloc0(&d_patches, M * d.kpad, stream));
     HIPCHK(dalloc0(&d_xh, M * d.D, stream));
-    HIPCHK(dalloc0(&d_xl, M * d.D, stream));
+    HIPCHK(dalloc0(&d_xl, M * d.D, stream));       // bytes
     HIPCHK(dalloc0(&d_cstat, M * (d.D / VT_STAT_CHUNK), stream));
     HIPCHK(dalloc0(&d_rstat, M + 1, stream));      // + 1: the 4-wave kernel fetches row terms as aligned pairs
     HIPCHK(dalloc0(&d_panel_cnt, (M + 255) / 256 + 1, stream));
@@ -333,10 +333,10 @@ int Engine::run_pass(Profiler* prof) {
     };
     auto tap = [&](int slot) {
         if (taps && lerr == hipSuccess) {     // both halves of the residual stream: [slot][hi | lo][M][D]
-            bf16_t* dst = d_taps + (size_t)slot * 2 * M * D;
+            uint8_t* dst = d_taps + (size_t)slot * tap_slot_bytes();
             lerr = hipMemcpyAsync(dst, d_xh, sizeof(bf16_t) * M * D, hipMemcpyDeviceToDevice, stream);
             if (lerr == hipSuccess)
-                lerr = hipMemcpyAsync(dst + (size_t)M * D, d_xl, sizeof(bf16_t) * M * D, hipMemcpyDeviceToDevice, stream);
+                lerr = hipMemcpyAsync(dst + sizeof(bf16_t) * M * D, d_xl, (size_t)M * D, hipMemcpyDeviceToDevice, stream);
         }
     };
     const int nchunk = D / VT_STAT_CHUNK;
@@ -381,7 +381,7 @@ int Engine::run_pass(Profiler* prof) {
     // K1: crop + resize + normalise the search window of every stream -> patch rows
     L("preproc_search", 0, (double)B * (d.S * d.S * 3 * 2 + 1.5 * d.S * d.S),
       [&] { return launch_preproc(d_frames, d_states, d_patches, d, 0, B, false, stream, crop_tier); });
-    // K2: patch embedding (+bias +pos) -> residual stream (bf16 pair + chunk statistics)
+    // K2: patch embedding (+bias +pos) -> residual stream (3-byte pair + chunk statistics)
     {
         GemmArgs a{};
         a.A = d_patches; a.lda = d.kpad;

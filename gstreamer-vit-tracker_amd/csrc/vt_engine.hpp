@@ -126,9 +126,12 @@ struct Engine {
     bf16_t *d_patches = nullptr, *d_qk = nullptr, *d_vt = nullptr,
            *d_attn = nullptr, *d_mlp = nullptr, *d_feat = nullptr, *d_ta = nullptr,
            *d_tb = nullptr, *d_zeros = nullptr;     // d_zeros: 256 B of zeros (out-of-map taps of the 3x3 convs)
-    // residual stream as a bf16 pair (x = xh + xl), its chunk partial statistics and the row terms of the
+    // residual stream as the 3-byte pair (x = xh + xl * 2^-12), its chunk partial statistics and the row terms of the
     // folded LayerNorm (vt_common.hpp); folded weights of all layers
-    bf16_t *d_xh = nullptr, *d_xl = nullptr, *d_foldw = nullptr, *d_taps = nullptr;
+    bf16_t *d_xh = nullptr, *d_foldw = nullptr;
+    uint8_t* d_xl = nullptr;                      // the low half of the pair: one signed byte per element (spec v3, vt_common.hpp)
+    uint8_t* d_taps = nullptr;                    // [slot][hi: M*D bf16 | lo8: M*D bytes]
+    size_t tap_slot_bytes() const { return (size_t)B * d.ntok * d.D * 3; }
     unsigned* d_band_cnt = nullptr;               // per stream: bands of the last head layer that have arrived (k_head.hip)
     float* d_band_best = nullptr;                 // per stream and band: the band's argmax candidate
     float2 *d_cstat = nullptr, *d_rstat = nullptr;

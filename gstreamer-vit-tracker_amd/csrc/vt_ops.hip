@@ -7,7 +7,7 @@ extern "C" {
 
 // ---- operator-level entry points ---------------------------------------------------------------------------
 
-// host-side helpers of the operator entry points: float32 <-> the bf16 pair of the residual stream
+// host-side helpers of the operator entry points: float32 <-> the 3-byte pair of the residual stream
 static inline bf16_t host_bf16(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -21,8 +21,8 @@ static inline float host_f32(bf16_t b) {
 }
 
 // epilogue: 0 x = acc + bias, 1 x = (acc + bias) + c_inout, 4 x = (acc + bias) + pos (pos = c_inout, one
-// row per output row) - the X-epilogues: c_inout goes in and comes back through the bf16 pair (hi + lo, 17
-// significant bits), rowstat_out (if given) receives the finalized row terms (rstd, -mean * rstd) of x;
+// row per output row) - the X-epilogues: c_inout goes in and comes back through the 3-byte pair (hi + lo8 * 2^-12: bf16 and
+// an absolute quantum of 2^-12), rowstat_out (if given) receives the finalized row terms (rstd, -mean * rstd) of x;
 // 2 gelu, 3 relu -> bf16, with an optional folded LayerNorm (rowstat_in [M][2], colsum [N]).
 int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const float* bias, float* c_inout,
                     int M, int N, int K, int epilogue, int cfg, const float* rowstat_in, const float* colsum,
@@ -42,7 +42,7 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
     HIPCHK(hipMemcpy(db.p, bias ? bias : zb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     GemmArgs g{};
     g.A = (const bf16_t*)da.p; g.lda = K; g.W = (const bf16_t*)dw.p; g.ldw = K; g.bias = (const float*)db.p;
-    g.M = M; g.N = N; g.K = K; g.Xh = (bf16_t*)dxh.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
+    g.M = M; g.N = N; g.K = K; g.Xh = (bf16_t*)dxh.p; g.Xl = (uint8_t*)dxl.p; g.ldx = N; g.Cb = (bf16_t*)dcb.p; g.ldcb = N;
     int epi;
     switch (epilogue) {
         case 0: epi = EPI_F32; break;
@@ -53,12 +53,18 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
         default: return set_err(VT_ERR_INVALID_ARG, "gemm: unknown epilogue %d", epilogue);
     }
     const bool x_epi = epi == EPI_F32 || epi == EPI_RESID || epi == EPI_F32_POS;
-    std::vector<bf16_t> hi, lo;
+    // the 3-byte pair of specification v3 (vt_common.hpp): hi = bf16(x), lo8 = clamp(rint((x - hi) * 2^12), -127, 127)
+    std::vector<bf16_t> hi;
+    std::vector<int8_t> lo;
     if (epi == EPI_RESID) {
         hi.resize(MN); lo.resize(MN);
-        for (size_t i = 0; i < MN; ++i) { hi[i] = host_bf16(c_inout[i]); lo[i] = host_bf16(c_inout[i] - host_f32(hi[i])); }
+        for (size_t i = 0; i < MN; ++i) {
+            hi[i] = host_bf16(c_inout[i]);
+            const float q = nearbyintf((c_inout[i] - host_f32(hi[i])) * 4096.0f);
+            lo[i] = (int8_t)(q < -127.0f ? -127.0f : q > 127.0f ? 127.0f : q);
+        }
         HIPCHK(hipMemcpy(dxh.p, hi.data(), MN * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dxl.p, lo.data(), MN * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dxl.p, lo.data(), MN, hipMemcpyHostToDevice));
     } else if (epi == EPI_F32_POS) {
         HIPCHK(dpos.alloc(MN * 4));
         HIPCHK(hipMemcpy(dpos.p, c_inout, MN * 4, hipMemcpyHostToDevice));
@@ -100,8 +106,8 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
     if (x_epi) {
         hi.resize(MN); lo.resize(MN);
         HIPCHK(hipMemcpy(hi.data(), dxh.p, MN * 2, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(lo.data(), dxl.p, MN * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < MN; ++i) c_inout[i] = host_f32(hi[i]) + host_f32(lo[i]);
+        HIPCHK(hipMemcpy(lo.data(), dxl.p, MN, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < MN; ++i) c_inout[i] = host_f32(hi[i]) + (float)lo[i] * VT_LO_Q;
         if (rowstat_out) HIPCHK(hipMemcpy(rowstat_out, dro.p, (size_t)M * 8, hipMemcpyDeviceToHost));
     } else {
         std::vector<bf16_t> tmp(MN);
@@ -146,7 +152,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     const bool x_epi = epilogue == EPI_F32 || epilogue == EPI_RESID || epilogue == EPI_F32_POS;
     DevBuf dcnt, dro;
     if (x_epi) {      // as the engine launches it: chunk partials + the row terms finalized by the last workgroup of each panel
-        g.Xh = (bf16_t*)dcb.p; g.Xl = (bf16_t*)dxl.p; g.ldx = N; g.cstat = (float2*)dcst.p;
+        g.Xh = (bf16_t*)dcb.p; g.Xl = (uint8_t*)dxl.p; g.ldx = N; g.cstat = (float2*)dcst.p;
         HIPCHK(dcnt.alloc((size_t)((M + 255) / 256 + 1) * 4)); HIPCHK(dro.alloc((size_t)M * 8 + 16));
         HIPCHK(hipMemset(dcnt.p, 0, (size_t)((M + 255) / 256 + 1) * 4));
         g.rowstat_out = (float2*)dro.p; g.panel_cnt = (unsigned*)dcnt.p; g.ln_eps = 1e-6f;
@@ -489,7 +495,7 @@ int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, con
 // The head's first layer with the final LayerNorm: out[b * ns + cell][n] = ReLU(LayerNorm(xh + xl)[b * ntok + off + cell] . w[n] + bias[n])
 // as bf16. fused != 0: one launch (the band kernel normalises its rows itself); fused == 0: the LayerNorm kernel, then the
 // band kernel on its output - the form the fused one must reproduce bit for bit. xh == nullptr: synthetic operands (timing).
-int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl, const float* gamma, const float* beta,
+int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const int8_t* xl, const float* gamma, const float* beta,
                            float eps, int ntok, int off, const uint16_t* w, const float* bias, float* out, int B, int grid,
                            int D, int N, int fused, int R, int ncb, int iters, float* us_out) try {
     const int ns = grid * grid;
@@ -506,7 +512,7 @@ int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl
     HIPCHK(dw.alloc((size_t)N * D * 2)); HIPCHK(db.alloc((size_t)N * 4)); HIPCHK(dfeat.alloc(M * D * 2)); HIPCHK(dout.alloc(M * N * 2));
     if (xh) {
         HIPCHK(hipMemcpy(dh.p, xh, Mx * D * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dl.p, xl, Mx * D * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dl.p, xl, Mx * D, hipMemcpyHostToDevice));       // lo8 bytes
         HIPCHK(hipMemcpy(dg.p, gamma, (size_t)D * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dbt.p, beta, (size_t)D * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dw.p, w, (size_t)N * D * 2, hipMemcpyHostToDevice));
@@ -529,14 +535,14 @@ int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl
     h.W = (const bf16_t*)dw.p; h.ldw = D; h.bias = (const float*)db.p; h.out = (bf16_t*)dout.p; h.ldout = N;
     h.B = B; h.grid = grid; h.C = N; h.N = N; h.K = D; h.conv3x3 = 0; h.R = R; h.ncb = ncb;
     if (fused) {
-        h.xh = (const bf16_t*)dh.p; h.xl = (const bf16_t*)dl.p; h.ln_g = (const float*)dg.p; h.ln_b = (const float*)dbt.p;
+        h.xh = (const bf16_t*)dh.p; h.xl = (const uint8_t*)dl.p; h.ln_g = (const float*)dg.p; h.ln_b = (const float*)dbt.p;
         h.ln_eps = eps; h.in_stride = ntok; h.in_off = off;
     } else {
         h.in = (const bf16_t*)dfeat.p; h.ldin = D;
     }
     auto run = [&]() -> hipError_t {
         if (!fused) {
-            hipError_t e = launch_layernorm_split((const bf16_t*)dh.p, (const bf16_t*)dl.p, (const float*)dg.p, (const float*)dbt.p,
+            hipError_t e = launch_layernorm_split((const bf16_t*)dh.p, (const uint8_t*)dl.p, (const float*)dg.p, (const float*)dbt.p,
                                                   (bf16_t*)dfeat.p, (int)M, D, ns, ntok, off, eps, nullptr);
             if (e != hipSuccess) return e;
         }

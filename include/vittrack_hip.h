@@ -395,8 +395,8 @@ int vt_group_set_state_box(vt_group* g, int stream, const float* box4);
 
 /* Copy an intermediate tensor of the last pass to the host as float32.
  * names: "patches" [N,Kpad], "tokens0" [N,D], "layer<i>" [N,D] (residual stream after block i;
- * both need taps), "x" [N,D] (final residual stream; like the taps the sum of the bf16 pair it is stored
- * as), "rowstat" [N,2] (row terms of the last folded LayerNorm), "attn" [N,D] (last block's attention output),
+ * both need taps), "x" [N,D] (final residual stream; like the taps the value of the 3-byte pair it is stored
+ * as: bf16 + a signed byte in units of 2^-12), "rowstat" [N,2] (row terms of the last folded LayerNorm), "attn" [N,D] (last block's attention output),
  * "feat" [Ns,D], "head_t3" [Ns,C], "head_out" [Ns,8] (score,ox,oy,w,h logits),
  * "state" (the stream's device state record as raw 32-bit words), "graph_replays" [3] (passes replayed so far
  * per crop-buffer tier: which of the captured graphs ran).

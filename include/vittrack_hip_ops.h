@@ -21,8 +21,8 @@ extern "C" {
  * K % 64 == 0, N % 64 == 0. cfg: tile configuration as in vt_op_gemm_bench (< 0: the launcher's own
  * choice for the shape). epilogue:
  *   0  x = acc + bias                    the X-epilogues the engine keeps its residual stream with: x is
- *   1  x = (acc + bias) + c_inout        stored as a bf16 pair (hi = bf16(x), lo = bf16(x - hi)) and comes
- *   4  x = (acc + bias) + pos            back as hi + lo (17 significant bits); pos = c_inout, one row per
+ *   1  x = (acc + bias) + c_inout        stored as the 3-byte pair (hi = bf16(x), lo8 = clamp(rint((x - hi) * 2^12), +-127))
+ *   4  x = (acc + bias) + pos            and comes back as hi + lo8 * 2^-12; pos = c_inout, one row per
  *                                        output row. rowstat_out (may be NULL) receives per row the terms
  *                                        (rstd, -mean * rstd) of LayerNorm(x) with `eps`, computed from the
  *                                        float32 x before the split (what the consuming GEMM multiplies with).
@@ -53,11 +53,11 @@ int vt_op_conv3x3_relu_bf16(int device_id, const uint16_t* t, const uint16_t* w,
 int vt_op_headconv_bf16(int device_id, const uint16_t* t, const uint16_t* w, const float* bias, float* out,
                         int B, int grid, int Cin, int N, int conv3x3, int R, int ncb, int iters, float* us_out);
 /* The head's first (1x1) layer with the final LayerNorm in front of it: out[b*grid*grid + cell][n] =
- * relu(LayerNorm(xh + xl)[b*ntok + off + cell] . w[n] + bias[n]); xh / xl [B*ntok][D] the bf16 pair of the residual
- * stream, gamma / beta [D], w [N][D], D = 768 or 1024. fused != 0: ONE launch - the band kernel normalises its band's
+ * relu(LayerNorm(xh + xl * 2^-12)[b*ntok + off + cell] . w[n] + bias[n]); xh (bf16 bits) / xl (signed bytes) [B*ntok][D] the
+ * 3-byte pair of the residual stream, gamma / beta [D], w [N][D], D = 768 or 1024. fused != 0: ONE launch - the band kernel normalises its band's
  * rows itself (what the engine runs); fused == 0: the LayerNorm kernel, then the band kernel on its output - the fused
  * form reproduces it bit for bit. R / ncb / iters / us_out / out as above; xh == NULL: synthetic operands (timing). */
-int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const uint16_t* xl, const float* gamma, const float* beta,
+int vt_op_headconv_ln_bf16(int device_id, const uint16_t* xh, const int8_t* xl, const float* gamma, const float* beta,
                            float eps, int ntok, int off, const uint16_t* w, const float* bias, float* out, int B, int grid,
                            int D, int N, int fused, int R, int ncb, int iters, float* us_out);
 /* The QKV projection with its attention-layout epilogue: a [B*tokens, D], w [3D, D], bias [3D] ->

@@ -11,11 +11,12 @@ What it follows:
     definition — the reference runs an un-vendored RKNN model. It follows this
     build's specification in DESIGN.md §2/§3. PARITY UNPINNED against the reference.
 
-Quantisation points mirror the HIP path ("numerical specification v2"):
+Quantisation points mirror the HIP path ("numerical specification v3"):
 GEMM operands are bf16 (weights are stored bf16; activations are rounded to bf16 exactly where the
 HIP kernels round them), accumulation, LayerNorm statistics and softmax are float32. The residual
-stream x is kept as a PAIR of bf16 tensors, hi = bf16(x) and lo = bf16(x - hi) (17 significant
-bits), and the two LayerNorms of a block are folded into the GEMM that consumes them: the GEMM's
+stream x is kept as a 3-BYTE PAIR, hi = bf16(x) and lo8 = clamp(rint((x - hi) * 2^12), -127, 127) as a signed
+byte (x = hi + lo8 * 2^-12: an absolute quantum of 2^-12 beside bf16's relative 2^-9; numerical specification v3,
+round 6 - until round 5 the low half was a second bf16), and the two LayerNorms of a block are folded into the GEMM that consumes them: the GEMM's
 A operand is hi itself, its weights are W' = bf16(gamma * W), and the epilogue applies
     y[m][n] = rstd[m] * (sum_k hi[m][k] W'[n][k] - mean[m] * s[n]) + c[n],
     s[n] = sum_k W'[n][k],  c[n] = sum_k beta[k] W[n][k] + bias[n]
@@ -230,12 +231,25 @@ def layernorm(x, g, b, eps):
     return ((x.astype(np.float32) - mean) * rstd) * g.reshape(1, -1) + b.reshape(1, -1)
 
 
+# numerical specification v3 (round 6): the low half of the residual pair is ONE byte - a signed integer in
+# units of 2^-12
+LO_SHIFT = 12
+LO_Q = np.float32(2.0 ** -LO_SHIFT)
+
+
 def split_residual(v):
-    """the residual stream as the bf16 pair the HIP path stores: hi = bf16(v), lo = bf16(v - hi)"""
+    """the residual stream as the 3-byte pair the HIP path stores: hi = bf16(v) and lo8 = clamp(rint((v - hi) * 2^12),
+    -127, 127) as a signed byte; returned as (hi, lo8 * 2^-12) in float32. Every step is exact but the two roundings
+    (v - hi is exact: hi is v rounded to 8 significant bits; the scaling is a power of two; rint is round-to-nearest-even;
+    hi + lo8 * 2^-12 is exact in float32 for |v| < 2^11), so an implementation cannot differ from this one by anything
+    but the value of v it starts from. |v - hi| <= ulp(hi) / 2 <= 127 * 2^-12 holds for |v| < 16; beyond that the clamp
+    leaves part of the low half behind (the value degrades towards bf16, it never wraps)."""
     v = v.astype(np.float32)
     hi = bf16r(v)
-    lo = bf16r((v - hi).astype(np.float32))
-    return hi, lo
+    if not ROUNDING:
+        return hi, np.zeros_like(hi)
+    lo8 = np.clip(np.rint((v - hi).astype(np.float32) * np.float32(2.0 ** LO_SHIFT)), -127.0, 127.0).astype(np.float32)
+    return hi, (lo8 * LO_Q).astype(np.float32)
 
 
 def fold_layernorm(w, gamma, beta, bias):

@@ -15,6 +15,12 @@ def _bits(vt, x):
     return vt.weights.f32_to_bf16_bits(np.asarray(x, np.float32))
 
 
+# Exact-integer tests of the X-epilogues (the GEMMs that write the residual stream): since round 6 that stream is the 3-byte
+# pair hi (bf16) + lo8 * 2^-12 (numerical specification v3), which holds every multiple of 2^-12 below 16 exactly - so the
+# integer operands are scaled by 2^-12 on the W / bias / addend side (a power of two: every product and sum stays exact)
+SC = np.float32(2.0 ** -12)
+
+
 def _rand_bf16(vt, rng, shape, scale=1.0):
     x = (rng.standard_normal(shape) * scale).astype(np.float32)
     b = _bits(vt, x)
@@ -97,9 +103,9 @@ def test_gemm_4wave_exact_integers(gpu, M, N, K, cfg):
     bias = rng.integers(-8, 9, size=N).astype(np.float32)
     c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
     ref = a @ w.T + bias
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0, cfg=cfg), ref)
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1,
-                                           cfg=cfg), ref + c0)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w * SC), bias * SC, epilogue=0, cfg=cfg), ref * SC)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w * SC), bias * SC, c_init=c0 * SC, epilogue=1,
+                                           cfg=cfg), (ref + c0) * SC)
     got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3, cfg=cfg)
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
@@ -117,9 +123,9 @@ def test_gemm256_exact_integers(gpu, M, N, K, cfg):
     bias = rng.integers(-8, 9, size=N).astype(np.float32)
     c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
     ref = a @ w.T + bias
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=0, cfg=cfg), ref)
-    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, c_init=c0, epilogue=1,
-                                           cfg=cfg), ref + c0)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w * SC), bias * SC, epilogue=0, cfg=cfg), ref * SC)
+    assert np.array_equal(gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w * SC), bias * SC, c_init=c0 * SC, epilogue=1,
+                                           cfg=cfg), (ref + c0) * SC)
     got = gpu.op_gemm_bf16(_bits(gpu, a), _bits(gpu, w), bias, epilogue=3, cfg=cfg)
     assert np.array_equal(got, bf16_round(np.maximum(ref, 0)))
 
@@ -136,12 +142,12 @@ def test_gemm256_full_chip_exact_integers(gpu, cfg):
     w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
     bias = rng.integers(-8, 9, size=N).astype(np.float32)
     ref = a @ w.T + bias          # |sums| <= 12,296: exact in float32 in any order
-    ab, wb = _bits(gpu, a), _bits(gpu, w)
+    ab, wb, wbs = _bits(gpu, a), _bits(gpu, w), _bits(gpu, w * SC)
     for _ in range(3):
-        got = gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg)
-        assert np.array_equal(got, ref)
+        got = gpu.op_gemm_bf16(ab, wbs, bias * SC, epilogue=0, cfg=cfg)
+        assert np.array_equal(got, ref * SC)
     c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
-    assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=1, cfg=cfg), ref + c0)
+    assert np.array_equal(gpu.op_gemm_bf16(ab, wbs, bias * SC, c_init=c0 * SC, epilogue=1, cfg=cfg), (ref + c0) * SC)
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=cfg), bf16_round(np.maximum(ref, 0)))
 
 
@@ -463,8 +469,8 @@ def test_head_band_kernel_with_the_final_layernorm_inside(gpu, B, grid, D, N, nt
          rng.standard_normal((B * ntok, 1))).astype(np.float32)
     xh = _bits(gpu, x)
     xhf = gpu.weights.bf16_bits_to_f32(xh)
-    xl = _bits(gpu, x - xhf)
-    xlf = gpu.weights.bf16_bits_to_f32(xl)
+    xl = np.clip(np.rint((x - xhf).astype(np.float32) * np.float32(4096.0)), -127, 127).astype(np.int8)      # the pair's lo8 bytes
+    xlf = xl.astype(np.float32) * SC
     gamma = (1.0 + 0.2 * rng.standard_normal(D)).astype(np.float32)
     beta = (0.1 * rng.standard_normal(D)).astype(np.float32)
     wb, w = _rand_bf16(gpu, rng, (N, D), 0.05)
@@ -512,13 +518,15 @@ def test_gemm256_persistent_qkv_and_activation_full_chip(gpu, tokens, B):
         assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=3, cfg=19), ref)
 
 
-# ---- the split residual stream and the folded LayerNorm (numerical spec v2) -------
+# ---- the split residual stream (numerical spec v3: 3-byte pair) and the folded LayerNorm -------
 
 def _split_pair(x):
-    """float32 -> hi + lo as the engine stores the residual stream (two bf16 roundings)"""
+    """float32 -> hi + lo8 * 2^-12 as the engine stores the residual stream (numerical specification v3: hi = bf16(x),
+    lo8 = clamp(rint((x - hi) * 2^12), -127, 127) as a signed byte)"""
     x = np.asarray(x, np.float32)
     hi = bf16_round(x)
-    return hi + bf16_round(x - hi)
+    lo8 = np.clip(np.rint((x - hi).astype(np.float32) * np.float32(4096.0)), -127, 127).astype(np.float32)
+    return (hi + lo8 * SC).astype(np.float32)
 
 
 def _row_terms(x, eps=1e-6):
@@ -532,7 +540,7 @@ def _row_terms(x, eps=1e-6):
 @pytest.mark.parametrize("epi", [0, 1, 4])
 def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
     """the three epilogues that write the residual stream (0 plain, 1 += old pair, 4 += positional rows):
-    the value comes back as the bf16 pair of the float32 result, and the finalized row terms of the
+    the value comes back as the 3-byte pair of the float32 result, and the finalized row terms of the
     LayerNorm that follows equal NumPy's (float64) on that float32 result - on a ragged M, every tile
     configuration, a row mean that is NOT small against the spread (chunk-wise combination must not
     cancel)"""
@@ -546,7 +554,9 @@ def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
     v = z if epi == 0 else (z + (_split_pair(c0) if epi == 1 else c0)).astype(np.float32)
     got, rs = gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=epi, cfg=cfg, want_rowstat=True)
     assert np.abs(got - v).max() < 2e-3                                # accumulation order
-    assert np.all(np.abs(got - _split_pair(got)) == 0)                 # it IS a bf16 pair
+    assert np.all(np.abs(got - _split_pair(got)) == 0)                 # it IS a 3-byte pair
+    # ... and the pair OF the float32 result: at most one quantum of the low half from the float32 reference's
+    assert np.abs(got - _split_pair(v)).max() <= 2e-3 + float(SC)
     ref = _row_terms(v)
     assert np.abs(rs[:, 0] / ref[:, 0] - 1).max() < 2e-5, np.abs(rs[:, 0] / ref[:, 0] - 1).max()
     assert np.abs(rs[:, 1] - ref[:, 1]).max() < 2e-4 * np.abs(ref[:, 1]).max()
@@ -554,7 +564,7 @@ def test_x_epilogues_pair_and_row_statistics(gpu, cfg, epi):
 
 @pytest.mark.parametrize("cfg", [0, 2, 3, 5, 18])
 def test_x_epilogues_exact_integers(gpu, cfg):
-    """small-integer operands: every sum is exact and fits the 16 significant bits of the pair, so the
+    """small-integer operands (scaled by 2^-12, see SC): every sum is exact and representable by the pair, so the
     X-epilogues must return the exact integers (a mis-staged row, a swapped hi / lo or a wrong addend
     row is a wrong integer), the positional variant with a period shorter than M included"""
     rng = np.random.default_rng(cfg)
@@ -563,8 +573,8 @@ def test_x_epilogues_exact_integers(gpu, cfg):
     w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
     bias = rng.integers(-8, 9, size=N).astype(np.float32)
     c0 = rng.integers(-100, 100, size=(M, N)).astype(np.float32)
-    ref = a @ w.T + bias
-    ab, wb = _bits(gpu, a), _bits(gpu, w)
+    ref = (a @ w.T + bias) * SC
+    ab, wb, bias, c0 = _bits(gpu, a), _bits(gpu, w * SC), bias * SC, c0 * SC
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, epilogue=0, cfg=cfg), ref)
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=1, cfg=cfg), ref + c0)
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=4, cfg=cfg), ref + c0)

@@ -189,10 +189,24 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def _assert_same_pair(got, want):
+    """the first tensor of the residual stream (patch embedding + bias + positions), HIP against the oracle: both round the
+    same float32 value - up to its summation order - to the 3-byte pair hi + lo8 * 2^-12 (numerical specification v3), so
+    an element either agrees exactly or sits ONE quantum of the low half away (a rounding boundary in between: 2^-12
+    absolute, 8.6e-5 of this tensor's maximum; until round 5, with a bf16 low half, the bar was 2e-5 of the maximum), and
+    such elements are few"""
+    d = np.abs(got - want)
+    assert d.max() <= 2.0 ** -12 * 1.0001, d.max()
+    assert (d > 0).mean() < 0.02, (d > 0).mean()
+
+
 # residual stream (max over blocks), final features, head logits: relative to the tensor's maximum
 # measured (round 3, spec v2): tiny 1.2e-4 / 2.3e-3 / 1.0e-3, cfg2 1.2e-3 / 4.0e-3 / 4.4e-3,
 # cfg3 1.1e-3 / 3.9e-3 / 5.3e-3, cfg5 2.1e-3 / 4.1e-3 / 5.2e-3
-TAP_BARS = {"tiny": (5e-4, 6e-3, 3e-3), "cfg2": (3e-3, 8e-3, 1e-2), "cfg3": (3e-3, 8e-3, 1.2e-2),
+# round 6, specification v3 (3-byte residual pair, absolute quantum 2^-12): tiny 3.4e-4 / 4.7e-3 / 1.8e-3, cfg2 1.6e-3 / 4.0e-3 /
+# 4.5e-3, cfg3 1.3e-3 / 3.9e-3 / 5.1e-3, cfg5 2.7e-3 / 4.1e-3 / 6.1e-3 - only the tiny model's residual bar moved (5e-4 -> 1e-3:
+# its stream is small, one quantum is 1e-4 of its maximum)
+TAP_BARS = {"tiny": (1e-3, 6e-3, 3e-3), "cfg2": (3e-3, 8e-3, 1e-2), "cfg3": (3e-3, 8e-3, 1.2e-2),
             "cfg5": (5e-3, 9e-3, 1.2e-2)}
 
 
@@ -220,7 +234,7 @@ def test_network_stage_taps(gpu, oracle, cfg):
     assert np.array_equal(g.read_tensor("patches").reshape(n, mi.kpad),
                           oracle.bf16_bits_to_f32(ref.last["patches"]))
     tok0 = g.read_tensor("tokens0").reshape(n, d)
-    assert _rel(tok0, ref.last["tokens0"]) < 2e-5
+    _assert_same_pair(tok0, ref.last["tokens0"])
     # bars = 2-3 x what was measured (tools/arbiter.py): both implementations round
     # to bf16 at the same points, what differs is float32 summation order, so a one-ulp bf16 flip here and
     # there is all there is - a kernel that makes the stream ten times worse must fail
@@ -263,7 +277,7 @@ def test_network_stage_taps_on_the_30_stream_engine(gpu, oracle, weights_cfg3, B
     for i in (0, B - 1):
         assert np.array_equal(grp.read_tensor("patches", i).reshape(n, mi.kpad),
                               oracle.bf16_bits_to_f32(ref.last["patches"]))
-        assert _rel(grp.read_tensor("tokens0", i).reshape(n, d), ref.last["tokens0"]) < 2e-5
+        _assert_same_pair(grp.read_tensor("tokens0", i).reshape(n, d), ref.last["tokens0"])
         bar_x, bar_feat, bar_head = TAP_BARS["cfg3"]
         for l in range(mi.layers):
             assert _rel(grp.read_tensor(f"layer{l}", i).reshape(n, d), ref.last[f"layer{l}"]) < bar_x, (i, l)

@@ -59,7 +59,8 @@ def test_bf16_oracle_stays_within_bf16_noise_of_the_unquantised_answer(vt, oracl
     truth = torch_ref.TorchModel(weights).forward(patches)
     got = oracle.Model(weights).forward(patches, taps=True)
     L = trk.m.L
-    assert _rel(got["tokens0"], truth["tokens0"]) <= 2e-5            # only the bf16 pair's 2^-18 (measured 5e-6)
+    # only the 3-byte pair's half quantum, 2^-13 absolute (numerical specification v3; with the bf16 low half of rounds 3-5: 2^-18 relative)
+    assert np.abs(got["tokens0"] - truth["tokens0"]).max() <= 2.0 ** -13 * 1.01
     assert _rel(got[f"layer{L - 1}"], truth[f"layer{L - 1}"]) <= 4e-3      # measured 1.5e-3
     assert _rel(got["feat"], truth["feat"]) <= 8e-3                  # feat itself is rounded to bf16 (measured 3.1e-3)
     # the decision the tracker takes from the map is the same
