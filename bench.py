@@ -703,13 +703,13 @@ def run_rank(args):
                        f"{mi.search_size}x{mi.search_size}x3 bf16 patch rows", "us": us, "algorithmic_bytes": by,
                        "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS})
         # the GEMMs that write the residual stream with K = D (proj: 152 FLOP/B, under the chip's 312 FLOP/B
-        # balance) are byte-bound: operands once + the residual pair (bf16 hi + lo) read and written
+        # balance) are byte-bound: operands once + the 3-byte residual pair (bf16 hi + int8 lo) read and written
         for p in prof:
             if p["name"].startswith("gemm_bf16_xresid") and p["bytes"] > 0 and p["flops"] / p["bytes"] < 312.0:
                 us = p["ms"] * 1e3 / max(p["launches"], 1)
                 by = p["bytes"] / max(p["launches"], 1)
                 bk.append({"kernel": p["name"], "frame": f"{Bg} streams x {mi.tokens_template + mi.tokens_search} tokens, "
-                           "operands once + residual pair read and written", "us": us, "algorithmic_bytes": by,
+                           "operands once + 3-byte residual pair read and written", "us": us, "algorithmic_bytes": by,
                            "flop_per_byte": p["flops"] / p["bytes"],
                            "GBps": by / us / 1e3, "frac_of_peak": by / us / 1e3 / PEAK_HBM_GBS})
         out["byte_kernels"] = {"peak_GBps": PEAK_HBM_GBS, "kernels": bk}

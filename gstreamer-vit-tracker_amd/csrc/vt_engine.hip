@@ -326,9 +326,9 @@ int Engine::run_pass(Profiler* prof) {
     };
     auto gemm = [&](int epi, GemmArgs a) {
         const double fl = 2.0 * a.M * a.N * a.K;
-        // algorithmic bytes: operands once, output once; the residual pair is read and written (4 + 4 B)
+        // algorithmic bytes: operands once, output once; the 3-byte residual pair is read and written (3 + 3 B)
         const double by = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
-                          (epi == EPI_RESID ? 8.0 : epi == EPI_F32_POS ? 4.0 : 2.0) * a.M * a.N;
+                          (epi == EPI_RESID ? 6.0 : epi == EPI_F32_POS ? 3.0 : 2.0) * a.M * a.N;
         L(prof ? gemm_name(epi, a) : "", fl, by, [&] { return launch_gemm(a, epi, stream); });
     };
     auto tap = [&](int slot) {

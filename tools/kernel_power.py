@@ -50,8 +50,8 @@ D, MLP = 768, 3072
 kernels = [
     ("fc1 + GELU (256x256 persistent)", 2.0 * M * MLP * D, 2.0 * (M * D + MLP * D + M * MLP), lambda it: vt.op_gemm_bench(M, MLP, D, 2, -1, iters=it)),
     ("QKV (256x256 persistent)", 2.0 * M * 3 * D * D, 2.0 * (M * D + 3 * D * D + M * 3 * D), lambda it: vt.op_gemm_bench(M, 3 * D, D, 4, -1, iters=it)),
-    ("fc2 + residual (256x256)", 2.0 * M * D * MLP, 2.0 * (M * MLP + D * MLP) + 8.0 * M * D, lambda it: vt.op_gemm_bench(M, D, MLP, 1, -1, iters=it)),
-    ("proj + residual (256x256)", 2.0 * M * D * D, 2.0 * (M * D + D * D) + 8.0 * M * D, lambda it: vt.op_gemm_bench(M, D, D, 1, -1, iters=it)),
+    ("fc2 + residual (256x256)", 2.0 * M * D * MLP, 2.0 * (M * MLP + D * MLP) + 6.0 * M * D, lambda it: vt.op_gemm_bench(M, D, MLP, 1, -1, iters=it)),
+    ("proj + residual (256x256)", 2.0 * M * D * D, 2.0 * (M * D + D * D) + 6.0 * M * D, lambda it: vt.op_gemm_bench(M, D, D, 1, -1, iters=it)),
     ("attention (mode 3)", 4.0 * B * 720 * 720 * D, 8.0 * M * D, lambda it: vt.op_attention_bench(B, 720, 12, -1, iters=it)),
     ("nv12 -> rgb8, 30 x 1080p", 0.0, 1920 * 1080 * 4.5 * 30, lambda it: vt.op_nv12_to_rgb8_batch_bench(1920, 1080, 30, iters=it)),
 ]

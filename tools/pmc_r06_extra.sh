@@ -14,8 +14,8 @@ run fc2 python3 tools/one_gemm.py $M 768 3072 1 18 20
 run attn python3 tools/attn_bench.py 3 30
 run nv12b python3 tools/one_nv12_batch.py 1920 1080 30 20
 python3 tools/pmc_summary.py $OUT/qkv gemm256p_kernel $O/r06_qkv_pmc.json --family gemm_bf16_qkv_256x256pp_n2304k768 --streams 30 --algorithmic-bytes $((M*768*2 + 2304*768*2 + M*2304*2)) --command "python3 tools/one_gemm.py $M 2304 768 4 19 20" --kernel-sha "$SHA" > /dev/null
-python3 tools/pmc_summary.py $OUT/proj gemm256_kernel $O/r06_proj_pmc.json --family gemm_bf16_xresid_256x256pp_n768k768 --streams 30 --algorithmic-bytes $((M*768*2 + 768*768*2 + M*768*8)) --command "python3 tools/one_gemm.py $M 768 768 1 18 20" --kernel-sha "$SHA" > /dev/null
-python3 tools/pmc_summary.py $OUT/fc2 gemm256_kernel $O/r06_fc2_pmc.json --family gemm_bf16_xresid_256x256pp_n768k3072 --streams 30 --algorithmic-bytes $((M*3072*2 + 768*3072*2 + M*768*8)) --command "python3 tools/one_gemm.py $M 768 3072 1 18 20" --kernel-sha "$SHA" > /dev/null
+python3 tools/pmc_summary.py $OUT/proj gemm256_kernel $O/r06_proj_pmc.json --family gemm_bf16_xresid_256x256pp_n768k768 --streams 30 --algorithmic-bytes $((M*768*2 + 768*768*2 + M*768*6)) --command "python3 tools/one_gemm.py $M 768 768 1 18 20" --kernel-sha "$SHA" > /dev/null
+python3 tools/pmc_summary.py $OUT/fc2 gemm256_kernel $O/r06_fc2_pmc.json --family gemm_bf16_xresid_256x256pp_n768k3072 --streams 30 --algorithmic-bytes $((M*3072*2 + 768*3072*2 + M*768*6)) --command "python3 tools/one_gemm.py $M 768 3072 1 18 20" --kernel-sha "$SHA" > /dev/null
 python3 tools/pmc_summary.py $OUT/attn attention_dma_kernel $O/r06_attention_pmc.json --family attention --streams 30 --algorithmic-bytes $((M*768*2*4)) --command "python3 tools/attn_bench.py 3 30" > /dev/null
 python3 tools/pmc_summary.py $OUT/nv12b nv12_to_rgb8_batch_kernel $O/r06_nv12_batch_pmc.json --family nv12_to_rgb8_batch --streams 30 --algorithmic-bytes $((1920*1080*9/2*30)) --command "python3 tools/one_nv12_batch.py 1920 1080 30 20" > /dev/null
 for f in qkv proj fc2 attention nv12_batch; do python3 -c "
