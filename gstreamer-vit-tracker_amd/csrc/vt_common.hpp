@@ -62,11 +62,13 @@ struct ModelDims {
 // Xl = lo8 [M][ldx] bytes, lo8 = clamp(rint((x - Xh) * 2^12), -127, 127) as a signed integer: x = Xh + lo8 * 2^-12.
 // Until round 5 the low half was a second bf16 (4 bytes per element, 17 significant bits); the byte plane moves a
 // quarter less through the X-epilogues' read-modify-write and the final LayerNorm, the phases of the pass that are
-// bound by memory requests (profiles/r06_lo8_residual.txt: whole frame + 3 %). x - Xh is exact (Xh is x rounded to 8
+// bound by memory requests (profiles/r06_lo8_residual.txt: whole frame + 2.0 %). x - Xh is exact (Xh is x rounded to 8
 // significant bits), the scaling is a power of two, rint is round-to-nearest-even, Xh + lo8 * 2^-12 is exact in
 // float32: oracle (oracle/vit_ref.py split_residual) and kernels can differ only through the x they start from.
-// |x - Xh| <= 127 * 2^-12 holds for |x| < 16 (this model: |x| < 3.5); beyond it the clamp leaves part of the low half
-// behind - the value degrades towards plain bf16, it never wraps.
+// |x - Xh| <= ulp(Xh) / 2: at most 64 quanta for |x| < 8 (this model: |x| < 3.5) - the byte holds it with room to spare
+// and the stored value is within half a quantum of x. For 8 <= |x| < 16 the remainder reaches 128 quanta next to a bf16
+// tie, where the clamp costs at most one quantum; beyond 16 it leaves part of the low half behind - the value degrades
+// towards plain bf16, it never wraps.
 #define VT_LO_SHIFT 12
 #define VT_LO_Q (1.0f / 4096.0f)
 #define VT_LO_MAX (127.0f / 4096.0f)

@@ -242,8 +242,10 @@ def split_residual(v):
     -127, 127) as a signed byte; returned as (hi, lo8 * 2^-12) in float32. Every step is exact but the two roundings
     (v - hi is exact: hi is v rounded to 8 significant bits; the scaling is a power of two; rint is round-to-nearest-even;
     hi + lo8 * 2^-12 is exact in float32 for |v| < 2^11), so an implementation cannot differ from this one by anything
-    but the value of v it starts from. |v - hi| <= ulp(hi) / 2 <= 127 * 2^-12 holds for |v| < 16; beyond that the clamp
-    leaves part of the low half behind (the value degrades towards bf16, it never wraps)."""
+    but the value of v it starts from. |v - hi| <= ulp(hi) / 2, i.e. at most 64 quanta for |v| < 8: the stored value is
+    within half a quantum of v. For 8 <= |v| < 16 the remainder reaches 128 quanta next to a bf16 tie, where the clamp
+    costs at most one quantum; beyond 16 it leaves part of the low half behind (the value degrades towards bf16, it
+    never wraps). tests/test_weights_and_oracle_model.py holds known answers for each of these cases."""
     v = v.astype(np.float32)
     hi = bf16r(v)
     if not ROUNDING:

@@ -580,6 +580,33 @@ def test_x_epilogues_exact_integers(gpu, cfg):
     assert np.array_equal(gpu.op_gemm_bf16(ab, wb, bias, c_init=c0, epilogue=4, cfg=cfg), ref + c0)
 
 
+@pytest.mark.parametrize("cfg", [0, 2, 5, 8, 18])
+def test_x_epilogues_encode_every_float_like_the_specification(gpu, cfg):
+    """the encoder of the 3-byte pair, value by value: with zero operands the X-epilogue's result is its float32 bias
+    (the accumulators' initial value), so ANY float32 can be put through the kernel's split - ordinary values, bf16 ties,
+    ties of the byte's own rounding, the band 8 <= |x| < 16 where the remainder reaches 128 quanta and the clamp bites,
+    values far beyond 16 (saturation, never a wrap), tiny values and zeros of both signs: every one must come back as
+    exactly the pair the specification defines (`_split_pair`; oracle/vit_ref.py split_residual is the same arithmetic)"""
+    rng = np.random.default_rng(77 + cfg)
+    M, N, K = 300, 768, 256
+    Q = np.float32(SC)
+    hand = np.array([1.0, 1.0 + 3 * Q, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -8 + Q, -2.5 - 2.5 * Q, 2.5 + 3.5 * Q, 0.375 * Q, -0.5 * Q,
+                     1.5 * Q, 0.0, -0.0, 15.96875, -15.96875, 8.0 + 2.0 ** -5, 8.0 + 2.0 ** -5 - Q / 4, 40.0625, -40.0625,
+                     1000.3, -3.0e4, 127.5 * Q, 128.5 * Q], np.float32)
+    ties16 = np.float32(8.0) + (np.arange(64, dtype=np.float32) * 2 + 1) * np.float32(2.0 ** -5)
+    bias = np.concatenate([hand, ties16, -ties16, rng.normal(0, 0.65, 200).astype(np.float32),
+                           (rng.uniform(8, 16, 200) * rng.choice([-1, 1], 200)).astype(np.float32),
+                           (rng.uniform(16, 300, 100) * rng.choice([-1, 1], 100)).astype(np.float32)])
+    bias = np.concatenate([bias, rng.uniform(-4, 4, N - len(bias)).astype(np.float32)])
+    zeros_a, zeros_w = np.zeros((M, K), np.float32), np.zeros((N, K), np.float32)
+    want = np.broadcast_to(_split_pair(bias), (M, N))
+    for epi, c0 in ((0, None), (1, np.zeros((M, N), np.float32))):
+        got = gpu.op_gemm_bf16(_bits(gpu, zeros_a), _bits(gpu, zeros_w), bias, c_init=c0, epilogue=epi, cfg=cfg)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (epi, bad[:4], got[tuple(bad[0])], want[tuple(bad[0])], bias[bad[0][1]])
+    assert np.abs(want[0, :len(hand)] - hand)[:9].max() <= float(Q) / 2            # ordinary values: half a quantum
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 18, 19])
 @pytest.mark.parametrize("epi", [2, 3])
 def test_folded_layernorm_in_the_bf16_epilogues(gpu, cfg, epi):

@@ -71,12 +71,13 @@ BARS = {"traj_cfg3_300.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg3_300_b.npz": dict(px=1, min_iou=0.90, mean_iou=0.99),
         "traj_cfg2_300_b.npz": dict(px=1, min_iou=0.88, mean_iou=0.99),
         "traj_cfg5_300_b.npz": dict(px=1, min_iou=0.95, mean_iou=0.99)}
-# Frames with IoU(hip, oracle) < 0.99 (a box off by one pixel in one coordinate): MEASURED counts of round 3's final
-# run (profiles/r03_gpu_tests.log) for the single tracker / the recommended-size engine. +-1 px is the guarantee, so a
-# kernel change that moves one bf16 rounding may legitimately move a few of these frames: the bar is the measured
-# count + max(2, 25 %) (round-4 advice), printed beside the measurement.
-LOW_IOU_MEASURED = {"traj_cfg3_300.npz": (1, 1), "traj_cfg2_300.npz": (1, 1), "traj_cfg5_300.npz": (8, 22),
-                    "traj_cfg3_300_b.npz": (5, 6), "traj_cfg2_300_b.npz": (0, 0), "traj_cfg5_300_b.npz": (3, 4)}
+# Frames with IoU(hip, oracle) < 0.99 (a box off by one pixel in one coordinate): MEASURED counts of round 6's final
+# run (profiles/r06_gpu_tests.log; fixtures and kernels on numerical specification v3) for the single tracker / the
+# recommended-size engine. +-1 px is the guarantee, so a kernel change that moves one bf16 rounding may legitimately move a
+# few of these frames: the bar is the measured count + max(2, 25 %) (round-4 advice), printed beside the measurement.
+# (rounds 3-5, specification v2: cfg3 1/1, cfg2 1/1, cfg5 8/22, cfg3_b 5/6, cfg2_b 0/0, cfg5_b 3/4)
+LOW_IOU_MEASURED = {"traj_cfg3_300.npz": (1, 0), "traj_cfg2_300.npz": (0, 1), "traj_cfg5_300.npz": (10, 10),
+                    "traj_cfg3_300_b.npz": (2, 2), "traj_cfg2_300_b.npz": (0, 0), "traj_cfg5_300_b.npz": (6, 7)}
 LOW_IOU_FRAMES = {k: tuple(c + max(2, (c + 3) // 4) for c in v) for k, v in LOW_IOU_MEASURED.items()}
 # result.score where both implementations evaluated the SAME input and picked the same cell: closed-loop frames
 # whose incoming state (the previous frame's integer box and success flag) is identical - then the crops are
@@ -441,8 +442,12 @@ def test_closed_loop_on_the_ill_conditioned_first_generation_head(gpu, capsys):
     down to 0.0008). HIP runs the same clip closed loop, single tracker and 30-stream engine. Measured (round 4,
     MI355X): 192 of 300 boxes identical, 66 off by 1 px, 27 by 2 px, 15 by 3-4 px, the two trajectories
     re-synchronise again and again (the last 30 frames are identical) - an ill-conditioned head turns one bf16
-    rounding flip into a few pixels for a few frames, where the shipped heads give +-1 px. This test REPORTS
-    that and BOUNDS it: no frame beyond 5 px, at most 8 % of the frames beyond 2 px, mean IoU >= 0.975, equal
+    rounding flip into a few pixels for a few frames, where the shipped heads give +-1 px. Round 6 (oracle and
+    kernels on the 3-byte residual pair; the fixture regenerated): 159 / 176 identical (1 / 30 streams), 18 / 13
+    frames at 3-5 px, min IoU 0.881 / 0.854 - another draw of the same noise: against the ground truth HIP reads
+    0.9665 / 0.9668 mean IoU where the oracle reads 0.9656. This test REPORTS
+    that and BOUNDS it: no frame beyond 6 px, at most 8 % of the frames beyond 2 px, mean IoU >= 0.975, min IoU
+    >= 0.82 (the oracle itself is at 0.879 against the truth), equal
     success flags - and, the yardstick that matters for such a head, HIP is as close to the GROUND TRUTH as
     the oracle is (mean IoU within 0.01): the divergence is inside the head's own noise."""
     fx = _fixture("forced_cfg3_300.npz")
@@ -472,9 +477,9 @@ def test_closed_loop_on_the_ill_conditioned_first_generation_head(gpu, capsys):
                   f"beyond 1 px at frame {int(np.argmax(d > 1)) if (d > 1).any() else -1}); IoU(hip, oracle) min "
                   f"{ious.min():.4f} mean {ious.mean():.5f}, frames below 0.99: {(ious < 0.99).sum()}; against the ground "
                   f"truth: oracle mean IoU {gt_oracle.mean():.4f} min {gt_oracle.min():.3f}, HIP mean {gt_hip.mean():.4f} "
-                  f"min {gt_hip.min():.3f}  [bars, set from the round-4 run: max <= 5 px, beyond 2 px <= {int(0.08 * n)} frames, "
-                  f"mean IoU >= 0.975, min IoU >= 0.85]")
-        assert d.max() <= 5, f"closed loop on the gen-1 head diverged by {d.max()} px at frame {int(d.argmax())}"
-        assert (d > 2).sum() <= 0.08 * n and ious.mean() >= 0.975 and ious.min() >= 0.85
+                  f"min {gt_hip.min():.3f}  [bars, set from the round-4 and round-6 runs: max <= 6 px, beyond 2 px <= {int(0.08 * n)} frames, "
+                  f"mean IoU >= 0.975, min IoU >= 0.82]")
+        assert d.max() <= 6, f"closed loop on the gen-1 head diverged by {d.max()} px at frame {int(d.argmax())}"
+        assert (d > 2).sum() <= 0.08 * n and ious.mean() >= 0.975 and ious.min() >= 0.82
         assert np.array_equal(np.array(succ), fx["success"].astype(int)), "success flags differ"
         assert abs(gt_hip.mean() - gt_oracle.mean()) <= 0.01 and gt_hip.min() > 0.5

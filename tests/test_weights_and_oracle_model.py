@@ -210,3 +210,41 @@ def test_make_traj_fbox_mode_reproduces_the_fixture_and_appends_float_boxes(vt, 
     np.savez_compressed(out, **b)
     with pytest.raises(AssertionError):
         mt.add_fbox("traj_tiny_6.npz")
+
+
+def test_residual_pair_v3_known_answers_and_properties(oracle):
+    """numerical specification v3: hi = bf16(x), lo8 = clamp(rint((x - hi) * 2^12), -127, 127), x' = hi +
+    lo8 * 2^-12. Known answers worked out by hand from the definition (bf16 keeps 8 significant bits, ties to even), then the
+    properties the kernels rely on: the reconstruction error is at most half a quantum for |x| < 8 and one quantum for |x| < 16 (the
+    clamp bites next to a bf16 tie), the byte saturates (never wraps) beyond, and the pair is idempotent."""
+    Q = 2.0 ** -12
+    kat = [  # x, hi, lo8
+        (1.0, 1.0, 0),
+        (1.0 + 3 * Q, 1.0, 3),                    # ulp(bf16) at 1.0 is 2^-7 = 32 quanta: well inside +-16
+        (1.0 + 2.0 ** -8 + Q, 1.0 + 2.0 ** -7, -15),       # above the midpoint: hi rounds up, the byte is negative (-16 + 1)
+        (1.0 + 2.0 ** -8, 1.0, 16),               # the bf16 tie goes to the even mantissa (1.0), the byte carries the half ulp
+        (-2.5 - 2.5 * Q, -2.5, -2),               # a tie of the BYTE: rint(-2.5) = -2 (to even)
+        (0.375 * Q, 0.375 * Q, 0),                # tiny values: hi is exact (0.375 has two significant bits), nothing is left over
+        (15.96875, 16.0, -127),                   # |x| < 16: x - hi = -2^-5 = -128 quanta ... the one value that clamps: -127
+        (40.0 + 0.0625, 40.0, 127),               # ulp 0.25: remainder 256 quanta, saturates at +127 (value degrades towards bf16)
+    ]
+    for x, hi_w, lo_w in kat:
+        hi, lo = oracle.split_residual(np.array([x], np.float32))
+        assert float(hi[0]) == np.float32(hi_w) and round(float(lo[0]) / Q) == lo_w, (x, float(hi[0]), float(lo[0]) / Q)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.normal(0, 0.65, 200000), rng.uniform(-7.99, 7.99, 200000)]).astype(np.float32)
+    hi, lo = oracle.split_residual(x)
+    assert np.array_equal(hi, oracle.bf16r(x)) and np.array_equal(lo / np.float32(Q), np.rint(lo / np.float32(Q)))
+    err = np.abs((hi + lo).astype(np.float64) - x.astype(np.float64))
+    assert err.max() <= Q / 2 * (1 + 1e-6), err.max()                    # half a quantum, nothing else
+    x16 = (rng.uniform(8, 15.99, 200000) * rng.choice([-1, 1], 200000)).astype(np.float32)
+    x16[:64] = np.float32(8.0) + (np.arange(64, dtype=np.float32) * 2 + 1) * np.float32(2.0 ** -5)      # the bf16 ties of [8, 12)
+    h16, l16 = oracle.split_residual(x16)
+    e16 = np.abs((h16 + l16).astype(np.float64) - x16.astype(np.float64))
+    assert Q / 2 < e16.max() <= Q, e16.max()                             # 128 quanta clamp to 127: one quantum at most
+    h2, l2 = oracle.split_residual((hi + lo).astype(np.float32))
+    assert np.array_equal((h2 + l2).astype(np.float32), (hi + lo).astype(np.float32))   # a stored value is a fixed point
+    big = rng.uniform(16, 3000, 20000).astype(np.float32) * rng.choice([-1, 1], 20000).astype(np.float32)
+    hb, lb = oracle.split_residual(big)
+    assert np.abs(lb).max() <= 127 * Q
+    assert (np.abs((hb + lb) - big) <= np.abs(hb - big)).all()           # saturated, the pair is never worse than bf16 alone
