@@ -383,8 +383,19 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
         const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    // Which operand an XCD's run shares (round 6): row panels x all columns re-reads ALL of W in every XCD (one stream, fc1:
+    // 8 x 4.7 MB for 1.1 MB of A); with few row panels a run of whole COLUMNS reads W / 8 + A per XCD instead (tile_order 2:
+    // fc1 of one stream 13.4 -> 11.7 us, QKV 9.6 -> 9.1; the residual GEMMs, A as large as W, keep the row runs; 2 x 4 and
+    // 4 x 2 blocks of the tile grid per XCD measured no better: profiles/r06_single_stream_experiments.txt)
+    int m0, n0;
+    if (p.tile_order == 2) {
+        const int tiles_m = (p.M + BM - 1) / BM;
+        m0 = (bid % tiles_m) * BM;
+        n0 = (bid / tiles_m) * BN;
+    } else {
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * BN;
+    }
     if constexpr (LW) {
         if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4) {     // loader waves (see gemm_lw_loader)
             gemm_lw_loader<BM, BN, NS, BK, EPI == EPI_RELU_BF16>(p, smem, m0, n0);
@@ -744,7 +755,8 @@ __global__ __launch_bounds__(WVM * WVN * 64 * (LW ? 2 : 1), 2) void gemm_bf16_ke
 //              residual GEMMs (proj, fc2: 144 tiles, one long tile per CU)
 //   8: 128x64  ring 3 k128 + 4 loader waves: fc2 of two / three streams
 // (measured and dropped, profiles/r05_loader_wave_small_batch.txt: 64x64 ring 4 / 6 k64 and ring 4 k128, 128x64 ring 4 k64,
-//  128x128 ring 4 k64 with loader waves)
+//  128x128 ring 4 k64 with loader waves; round 6, profiles/r06_single_stream_experiments.txt: 96x96 tiles on three waves -
+//  fc1 of one stream as ONE round of 256 tiles - ring 4 k64 and ring 3 k128: 15.2 us against 13.2)
 #define GEMM_FOR_EACH_CFG(X, EPI) \
     X(0, 64, 64, 2, 2, 4, 64, EPI, false)    \
     X(1, 128, 128, 2, 2, 3, 64, EPI, false)  \
@@ -794,8 +806,11 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t st) {
     if (a.conv_grid > 0 && a.conv_C % BK != 0) return hipErrorInvalidValue;   // a K-tile lies inside one tap
     if (EPI == EPI_QKV && a.D % BN != 0) return hipErrorInvalidValue;  // a column tile is q, k or v
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    GemmArgs b = a;
+    if (b.tile_order < 1 || b.tile_order > 2)     // QKV / fc1 of a few streams: A is the smaller operand, an XCD shares it whole
+        b.tile_order = ((EPI == EPI_QKV || EPI == EPI_GELU_BF16) && a.M < a.N) ? 2 : 1;
     vt_launch((gemm_bf16_kernel<BM, BN, WVM, WVN, NS, BK, EPI, LW>), dim3(tiles),
-                       dim3(WVM * WVN * 64 * (LW ? 2 : 1)), smem, st, a);
+                       dim3(WVM * WVN * 64 * (LW ? 2 : 1)), smem, st, b);
     return hipGetLastError();
 }
 

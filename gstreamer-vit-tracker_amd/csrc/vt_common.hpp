@@ -119,6 +119,9 @@ struct GemmArgs {
     // `zeros` (>= 128 B of zeros in device memory).
     int conv_grid, conv_C;
     const bf16_t* zeros;
+    // kernel of k_gemm.hip: which tiles an XCD's contiguous run of workgroups covers - 0: the launcher decides (bf16-output
+    // epilogues with M < N: column tiles), 1: row panels x all columns, 2: column tiles x all rows
+    int tile_order;
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, hipStream_t st);

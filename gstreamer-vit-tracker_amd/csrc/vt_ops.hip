@@ -161,6 +161,7 @@ int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, 
     g.pos = (const float*)dc.p; g.pos_rows = M;
     g.qk = (bf16_t*)dcb.p; g.vt = (bf16_t*)dvt.p; g.tokens = tokens; g.npad = npad; g.D = D;
     if (epilogue == EPI_QKV && (N % 192 || tokens != M)) return set_err(VT_ERR_INVALID_ARG, "qkv bench: N = 3D, D %% 64 == 0, M %% 4 == 0");
+    if (cfg >= 0) { g.tile_order = (cfg >> 8) & 3; cfg &= 0xff; }   // sweeps: bits 8-9 force the XCD tile order (1 rows, 2 columns)
     if (cfg < 0) cfg = gemm_pick_config(M, N, K, epilogue);
     DevBuf ddbg;
     const size_t dbg_words = (size_t)((M + 63) / 64) * (N / 64) * 8 * 4;

@@ -523,10 +523,11 @@ def test_dmabuf_import_roundtrip_tracks_like_the_source_buffer(gpu, weights_tiny
     import torch
     w, h = 640, 480
     sc = gpu.synth.MovingSquare(w, h, 64, seed=21)
-    nbytes = 1 << 21                                    # one 2 MiB allocation: page-aligned range
-    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
-    if buf.data_ptr() % 4096:
-        pytest.skip("allocator returned an unaligned block")
+    nbytes = 1 << 21                                    # a 2 MiB page-aligned range ...
+    raw = torch.zeros(nbytes + 4096, dtype=torch.uint8, device="cuda")
+    off = (-raw.data_ptr()) % 4096                      # ... inside a block the caching allocator may hand out at any 512-B offset
+    buf = raw[off:off + nbytes]
+    assert buf.data_ptr() % 4096 == 0
     try:
         fd = gpu.export_dmabuf(buf.data_ptr(), nbytes)
     except gpu.VtError as e:

@@ -2,7 +2,7 @@
 # round-6 measurement set on one MI355X box (run from the repository root): rocprofv3 kernel-trace summaries of bench.py
 # (one engine / two engines), PMC passes of the dominant kernel (tied to the kernel build through vt_build_info), the
 # per-kernel power table, the bench lines. Results under gpurun_out/r06/; what is judged is copied into profiles/ afterwards.
-#   PART=1 bash tools/profile_r06.sh   (traces + PMC)      PART=2 bash tools/profile_r06.sh   (bench lines)
+#   PART=1 bash tools/profile_r06.sh   (traces + PMC)      PART=2 ...   (bench lines)      PART=3 ...   (the driver's command x 3)      PART=4 ...   (PMC alone)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/r06
@@ -12,6 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_30x1 -- python3
 echo "trace 30x1 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_60x2 -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-host-leg --no-single-leg > $O/trace_60x2.json 2> $O/trace_60x2.err
 echo "trace 60x2 done"
+fi
+if [ "${PART:-1}" = "1" ] || [ "${PART:-1}" = "4" ]; then     # PMC passes of the dominant kernel (PART=4: these alone)
 OUT=gpurun_out/pmc_r06
 CGROUPS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"
         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
