@@ -83,6 +83,7 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
     // X-epilogues on the 256x256 kernel finalize the row terms themselves (last workgroup of each row panel)
     DevBuf dcnt;
     bool fused = false;
+    if (cfg >= 0) { g.tile_order = (cfg >> 8) & 3; cfg &= 0xff; }   // bits 8-9 of a given configuration: the XCD tile order (1 rows, 2 columns)
     if (x_epi && rowstat_out) {
         HIPCHK(dro.alloc((size_t)M * 8));
         HIPCHK(dcnt.alloc((size_t)((M + 255) / 256 + 1) * 4));
@@ -225,6 +226,7 @@ int vt_op_qkv_bf16(int device_id, const uint16_t* a, const uint16_t* w, const fl
         HIPCHK(hipMemcpy(dcs.p, colsum, (size_t)3 * D * 4, hipMemcpyHostToDevice));
         g.rowstat = (const float2*)drs.p; g.colsum = (const float*)dcs.p;
     }
+    if (cfg >= 0) { g.tile_order = (cfg >> 8) & 3; cfg &= 0xff; }   // as in vt_op_gemm_bf16
     if (cfg < 0) HIPCHK(launch_gemm(g, EPI_QKV, nullptr));
     else if (launch_gemm_cfg(g, EPI_QKV, cfg, nullptr) != hipSuccess)
         return set_err(VT_ERR_INVALID_ARG, "qkv: tile configuration %d does not fit this shape", cfg);

@@ -77,6 +77,28 @@ def test_qkv_every_tile_config(gpu, cfg):
     assert np.all(np.abs(vt_[:, :, :tokens] - v) <= np.abs(v) * 2 ** -8 + 1e-3)
 
 
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 7])
+def test_xcd_tile_order_changes_placement_only(gpu, cfg):
+    """GemmArgs.tile_order (round 6): whether an XCD's contiguous run of workgroups covers row panels x all columns (1) or
+    column tiles x all rows (2) decides which L2 sees which operand, never what a tile computes - both orders (forced through
+    bits 8-9 of the operator hook's configuration argument) and the launcher's own rule (0: column runs for the bf16-output
+    epilogues when M < N) must give the same bits, on a ragged M whose tile count is not a multiple of 8, for GELU and QKV"""
+    rng = np.random.default_rng(cfg)
+    M, N, K = 720 + 37, 1536, 256
+    ab, _ = _rand_bf16(gpu, rng, (M, K))
+    wb, _ = _rand_bf16(gpu, rng, (N, K), 0.05)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = [gpu.op_gemm_bf16(ab, wb, bias, epilogue=2, cfg=cfg | o) for o in (0x000, 0x100, 0x200)]
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    B, tokens, D = 3, 100, 512
+    ab, _ = _rand_bf16(gpu, rng, (B * tokens, D))
+    wb, _ = _rand_bf16(gpu, rng, (3 * D, D), 0.04)
+    bias = (rng.standard_normal(3 * D) * 0.1).astype(np.float32)
+    outs = [gpu.op_qkv_bf16(ab, wb, bias, B, tokens, D, cfg=cfg | o, vt_perm=1) for o in (0x000, 0x100, 0x200)]
+    for qk, vt_ in outs[1:]:
+        assert np.array_equal(qk, outs[0][0]) and np.array_equal(vt_, outs[0][1])
+
+
 def test_gemm_exact_integers_asymmetric(gpu):
     """A = identity-like selector, W asymmetric small integers: catches swapped row/col maps and
     any staging/swizzle mix-up exactly (all values are exact in bf16 and f32)."""
