@@ -84,6 +84,13 @@ int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out
     *fd_out = -1;
     if (int rc = check_device(device_id)) return rc;
     DEVICE_SCOPE(device_id);
+    {   // the handle names the allocation: a range that starts inside one is mapped back from the allocation's base by the
+        // importer (ROCm 7.2) - other bytes than the caller meant. Refused here instead of aliased there.
+        hipDeviceptr_t base = nullptr;
+        size_t span = 0;
+        if (hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)d_ptr) != hipSuccess || base != (hipDeviceptr_t)d_ptr || bytes > span)
+            return set_err(VT_ERR_INVALID_ARG, "export_dmabuf: the range must begin at the start of a device allocation and lie inside it");
+    }
     int fd = -1;
     hipError_t he = hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)d_ptr, bytes,
                                                    hipMemRangeHandleTypeDmaBufFd, 0);

@@ -274,8 +274,10 @@ int vt_group_graph_captures(const vt_group* g);
 typedef struct vt_extmem vt_extmem;
 int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr);
 void vt_release_dmabuf(vt_extmem* m);
-/* Export a range of a hipMalloc'ed allocation as a dma-buf fd (page-aligned pointer and size; the
- * caller closes the fd). Tooling: used by the tests to exercise the import path on this machine. */
+/* Export the head of a hipMalloc'ed allocation as a dma-buf fd: d_ptr must be the START of the allocation (the
+ * handle names the allocation, and an importer maps it from its base; a pointer inside one is refused with
+ * VT_ERR_INVALID_ARG), bytes a page multiple within it; the caller closes the fd. Tooling: used by the tests to
+ * exercise the import path on this machine. */
 int vt_export_dmabuf(int device_id, const void* d_ptr, size_t bytes, int* fd_out);
 
 /* ---- zero-copy ingest of host frames --------------------------------------------------------------

@@ -523,11 +523,15 @@ def test_dmabuf_import_roundtrip_tracks_like_the_source_buffer(gpu, weights_tiny
     import torch
     w, h = 640, 480
     sc = gpu.synth.MovingSquare(w, h, 64, seed=21)
-    nbytes = 1 << 21                                    # a 2 MiB page-aligned range ...
-    raw = torch.zeros(nbytes + 4096, dtype=torch.uint8, device="cuda")
-    off = (-raw.data_ptr()) % 4096                      # ... inside a block the caching allocator may hand out at any 512-B offset
-    buf = raw[off:off + nbytes]
-    assert buf.data_ptr() % 4096 == 0
+    # the export names a whole allocation: a range that starts inside one comes back mapped from the allocation's base (a
+    # page-aligned sub-range of a cached torch segment was tried: the mapping then aliases other bytes). So the buffer must be
+    # an allocation of its own - with the caching allocator's free blocks released first, a request of 32 MiB (beyond the size
+    # it serves from shared segments) is one
+    torch.cuda.empty_cache()
+    nbytes = 32 << 20
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    with pytest.raises(gpu.VtError):                    # a range that starts inside an allocation is refused, not aliased
+        gpu.export_dmabuf(buf.data_ptr() + 4096, 1 << 20)
     try:
         fd = gpu.export_dmabuf(buf.data_ptr(), nbytes)
     except gpu.VtError as e:
