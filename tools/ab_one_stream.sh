@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of two library builds on the one-stream legs of bench.py (alternating)
+# same-box A/B of two library builds on the one-stream legs of bench.py (alternating). The build to compare against is expected as
+# gstreamer-vit-tracker_amd/libvittrack_hip_before.so: check the other revision out into a git worktree, run __graft_entry__.build() there and
+# copy its libvittrack_hip.so under that name (built .so files travel to the GPU box with the tree)
 O=gpurun_out/r06; mkdir -p $O
 for r in 1 2 3; do
   for lib in libvittrack_hip_before.so libvittrack_hip.so; do
