@@ -36,7 +36,11 @@ int vt_op_gemm_bf16(int device_id, const uint16_t* a, const uint16_t* w, const f
  * operands. epilogue uses the library's internal numbering (0 f32+pos, 1 residual, 2 GELU, 3 ReLU,
  * 4 QKV, 5 f32); cfg: 0 = 64x64 ring 4, 1 = 128x128 ring 3, 2 = 64x64 ring 2, 3 = 128x128 ring 2
  * (K-tile depth 64); 4 = 64x64 ring 3, 5 = 64x64 ring 2, 6 = 128x128 ring 2 (K-tile depth 128, K % 128 == 0);
- * 18 / 19 = 256x256 8-wave kernels (one tile per workgroup / persistent); <0 = the launcher's own choice. */
+ * 7 = 64x64 ring 3 and 8 = 128x64 ring 3 with four loader waves (K-tile depth 128);
+ * 18 / 19 = 256x256 8-wave kernels (one tile per workgroup / persistent); <0 = the launcher's own choice.
+ * Bits 8-9 of a cfg >= 0 (here, in vt_op_gemm_bf16 and in vt_op_qkv_bf16) force the order in which an XCD's run of
+ * workgroups covers the tile grid of configurations 0-8: 0 = the launcher's rule, 1 = row panels x all columns,
+ * 2 = column tiles x all rows (placement only: the results are the same bits). */
 int vt_op_gemm_bench(int device_id, int M, int N, int K, int epilogue, int cfg, int iters,
                      float* us_out);
 /* The head's 3x3 convolution (zero padding) + bias + ReLU as the engine runs it - an implicit GEMM whose
