@@ -1,6 +1,7 @@
 // vt_abi.hip — the extern "C" boundary of include/vittrack_hip.h (every entry a function-try-block: nothing unwinds
 // into the host, /root/reference/Cargo.toml:37 panic = "abort").
 #include "vt_engine.hpp"
+#include <sys/stat.h>
 #include <unistd.h>
 
 extern "C" {
@@ -35,6 +36,13 @@ int vt_device_count(void) try {
 struct vt_extmem {
     int device;
     hipExternalMemory_t mem;
+    // the duplicate descriptor the import was given. ROCm 7.2 neither closes it at hipImportExternalMemory nor at
+    // hipDestroyExternalMemory (tools/dmabuf_fd_probe.py: it is still open after both - every import leaked one descriptor
+    // and with it a reference on the buffer), so the release closes it - but only while it still names the same open file
+    // (device and inode as at import), in case another runtime version closes it itself and the number has been reused
+    int fd;
+    dev_t st_dev;
+    ino_t st_ino;
 };
 
 int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void** d_ptr) try {
@@ -62,10 +70,13 @@ int vt_import_dmabuf(int device_id, int fd, size_t bytes, vt_extmem** out, void*
     he = hipExternalMemoryGetMappedBuffer(&p, mem, &bd);
     if (he != hipSuccess || !p) {
         (void)hipDestroyExternalMemory(mem);
+        (void)close(dupfd);         // nothing opened a descriptor in between: at worst EBADF
         return set_err(VT_ERR_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(he));
     }
-    vt_extmem* xm = new (std::nothrow) vt_extmem{device_id, mem};
-    if (!xm) { (void)hipDestroyExternalMemory(mem); return set_err(VT_ERR_OOM, "out of host memory"); }
+    struct stat sb;
+    const bool have_id = fstat(dupfd, &sb) == 0;
+    vt_extmem* xm = new (std::nothrow) vt_extmem{device_id, mem, have_id ? dupfd : -1, have_id ? sb.st_dev : 0, have_id ? sb.st_ino : 0};
+    if (!xm) { (void)hipDestroyExternalMemory(mem); (void)close(dupfd); return set_err(VT_ERR_OOM, "out of host memory"); }
     *out = xm;
     *d_ptr = p;
     return VT_OK;
@@ -76,6 +87,10 @@ void vt_release_dmabuf(vt_extmem* m) try {
     DeviceScope ds(m->device);             // the caller's current device is restored on return
     (void)hipDeviceSynchronize();          // no kernel of ours may still read the mapping
     (void)hipDestroyExternalMemory(m->mem);
+    if (m->fd >= 0) {
+        struct stat sb;
+        if (fstat(m->fd, &sb) == 0 && sb.st_dev == m->st_dev && sb.st_ino == m->st_ino) (void)close(m->fd);
+    }
     delete m;
 } VT_NOTHROW_VOID
 

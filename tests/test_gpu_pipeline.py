@@ -554,7 +554,10 @@ def test_dmabuf_import_roundtrip_tracks_like_the_source_buffer(gpu, weights_tiny
             a = t_src.update_nv12_device(buf.data_ptr(), buf.data_ptr() + w * h, w, h, w, w)
             b = t_map.update_nv12_device(mapped.ptr, mapped.ptr + w * h, w, h, w, w)
             assert a.success and a.bbox == b.bbox and abs(a.score - b.score) < 1e-6
+        before = set(os.listdir("/proc/self/fd"))
         mapped.close()
+        gone = before - set(os.listdir("/proc/self/fd"))
+        assert len(gone) == 1, f"the release closes the descriptor the import duplicated (ROCm keeps it open): {gone}"
     finally:
         os.close(fd)
 
