@@ -105,3 +105,15 @@ def test_header_is_strict_c99_and_gives_a_c_compiler_the_same_layouts(vt):
     assert got["vt_frame"] == ctypes.sizeof(vt.CFrame)
     assert got["vt_result"] == ctypes.sizeof(vt.CResult) and got["vt_bbox"] == 16
     assert got["abi"] == vt.lib().vt_abi_version() and got["max_streams"] == 1024
+
+
+def test_every_tool_script_compiles():
+    """tools/*.py are run by hand on GPU boxes: a syntax error there costs a box acquisition; shell tools get `bash -n`"""
+    import glob
+    import py_compile
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))):
+        py_compile.compile(f, doraise=True)
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.sh"))):
+        assert subprocess.run(["bash", "-n", f], capture_output=True).returncode == 0, f
